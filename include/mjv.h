@@ -1,0 +1,183 @@
+/*
+ * mjv.h - C ABI of libmjv_hip.so: the MI355X (gfx950) kernels under the MJ-VIDEO reward-scoring path.
+ *
+ * The reference (aiming-lab/MJ-Video) has no FFI: its boundary is the Python class API
+ * (scripts/model/moe_reward.py:137-297).  This library sits UNDER the Python mirror of that API
+ * (mj-video_amd/modeling.py) and replaces the PyTorch/cuBLAS/flash-attn ops the reference's forward
+ * reaches.  Every entry point cites the reference code it replaces (paths relative to
+ * /root/reference/scripts/model).
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers borrowed from the caller (PyTorch tensors); the library
+ *     allocates nothing; the caller keeps buffers alive until the stream has been synchronised;
+ *   - bf16 tensors are passed as `const uint16_t*` (raw bf16 bit patterns), row-major, with an explicit
+ *     leading dimension in ELEMENTS;
+ *   - every call only ENQUEUES on `stream` (a hipStream_t passed as void*; 0 = null stream) and never
+ *     synchronises; the library is stateless apart from the opt-in profiler, hence thread-safe per stream;
+ *   - return value 0 = ok, negative = error (MJV_E_*); `mjv_last_error()` gives a thread-local message.
+ *   - rounding points follow the reference's bf16 eager path (bf16 result after every torch op).
+ */
+#ifndef MJV_H_
+#define MJV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJV_ABI_VERSION 1
+
+enum {
+  MJV_OK = 0,
+  MJV_E_ARG = -1,     /* bad argument (shape/alignment/null) */
+  MJV_E_LAUNCH = -2,  /* HIP launch error */
+  MJV_E_UNSUPPORTED = -3
+};
+
+typedef uint16_t mjv_bf16;
+
+int mjv_abi_version(void);
+const char* mjv_last_error(void);
+/* name of the device architecture the code object was built for ("gfx950") */
+const char* mjv_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM:  C[M,N] = epilogue( A[M,K] @ W[N,K]^T )      (torch.nn.Linear layout: W is [out, in])
+ * replaces every nn.Linear / Conv2d-as-GEMM on the path:
+ *   internvl2/modeling_intern_vit.py:145-147,164 (patch embed), :196,208 (qkv, proj), :256-257 (fc1, fc2)
+ *   internvl2/modeling_internvl_chat.py:135-140 (mlp1)
+ *   internvl2/modeling_internlm2.py:301-307 (wqkv, wo), :256-258 (w1, w3, w2)
+ *   moe_reward.py:24-26 (gating hidden layers)
+ * Requirements: K % 64 == 0, N % 8 == 0, lda/ldw/ldc/ldr % 8 == 0, 16-byte aligned base pointers.
+ * ------------------------------------------------------------------------------------------- */
+enum mjv_epilogue {
+  MJV_EPI_BIAS = 0,       /* C = bf16(acc + bias)                       bias may be NULL            */
+  MJV_EPI_BIAS_GELU = 1,  /* C = bf16(gelu_erf(bf16(acc + bias)))       (F.gelu on the bf16 Linear)  */
+  MJV_EPI_BIAS_RELU = 2,  /* C = bf16(max(acc + bias, 0))                                           */
+  MJV_EPI_SCALE_RES = 3,  /* v = bf16(acc + bias); if scale: v = bf16(v * scale[n]); C = bf16(res + v) */
+  MJV_EPI_SILU_MUL = 4    /* W rows interleaved [16 x w1 | 16 x w3]...; C[M,N/2] =
+                             bf16( bf16(silu(bf16(acc_w1))) * bf16(acc_w3) )   (modeling_internlm2.py:262) */
+};
+
+typedef struct mjv_gemm_desc {
+  const mjv_bf16* A; int64_t lda;   /* activations [M][lda] */
+  const mjv_bf16* W; int64_t ldw;   /* weights     [N][ldw] */
+  mjv_bf16* C; int64_t ldc;         /* output rows            */
+  int32_t M, N, K;
+  int32_t epilogue;                 /* enum mjv_epilogue */
+  const mjv_bf16* bias;             /* [N] or NULL */
+  const mjv_bf16* scale;            /* [N] or NULL (LayerScale ls1/ls2, modeling_intern_vit.py:291,293) */
+  const mjv_bf16* res; int64_t ldr; /* residual rows or NULL */
+  int32_t res_mod, res_off;         /* res_mod > 0: residual row = res_off + (m % res_mod)   (pos-emb add) */
+  int32_t out_group, out_pad;       /* out_group > 0: out row = (m / out_group) * (out_group + out_pad) + out_pad
+                                       + m % out_group   (skip the CLS slot of every tile)               */
+  const int32_t* out_rows;          /* optional explicit output row per m (splice into <IMG_CONTEXT> rows,
+                                       modeling_internvl_chat.py:176-179); overrides out_group            */
+} mjv_gemm_desc;
+
+int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Flash-style attention over packed variable-length sequences (no N x N scores in HBM).
+ *   non-causal D=64 : internvl2/modeling_intern_vit.py:210-227 (_naive_attn) / :229-244 (_flash_attn)
+ *   causal GQA D=128: internvl2/modeling_internlm2.py:383-411 (eager) / :437-561 (flash varlen)
+ * Q/K/V/O are addressed as base + row * ld + head * head_stride (elements); K/V head = q_head / kv_group.
+ * score rounding: mode 0: s = bf16(acc * scale)   [(q*scale) @ k^T with scale a power of two]
+ *                 mode 1: s = bf16(bf16(acc) * scale)   [matmul, then / sqrt(D) in bf16]
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mjv_attn_desc {
+  const mjv_bf16 *Q, *K, *V;
+  mjv_bf16* O;
+  int64_t ldq, ldk, ldv, ldo;
+  int32_t q_head_stride, k_head_stride, v_head_stride, o_head_stride;
+  const int32_t* cu_seqlens;  /* [n_seqs + 1] packed row offsets (device) */
+  int32_t n_seqs, max_seqlen;
+  int32_t n_heads, kv_group;
+  int32_t head_dim;           /* 64 or 128 */
+  int32_t causal;
+  float scale;
+  int32_t score_round_mode;
+} mjv_attn_desc;
+
+int mjv_attention_bf16(const mjv_attn_desc* d, void* stream);
+
+/* LayerNorm over the last dim, fp32 statistics, bf16 out (nn.LayerNorm on bf16:
+ * modeling_intern_vit.py:291,293; modeling_internvl_chat.py:136).
+ * gather_grid > 0 selects the pixel-shuffle gather of modeling_internvl_chat.py:228-242,255-260:
+ * output row (tile, a2, b2) is the concatenation of the 4 source rows
+ * (2a2,2b2) (2a2,2b2+1) (2a2+1,2b2) (2a2+1,2b2+1) of a [tile][1 + grid*grid][dim/4] buffer (CLS skipped). */
+int mjv_layernorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy, const mjv_bf16* gamma,
+                       const mjv_bf16* beta, int32_t rows, int32_t dim, float eps, int32_t gather_grid,
+                       void* stream);
+
+/* InternLM2RMSNorm (modeling_internlm2.py:138-143): y = w * bf16(x * rsqrt(mean(x^2) + eps)).
+ * row_index (optional, device) gathers input rows: y[i] = norm(x[row_index[i]]). */
+int mjv_rmsnorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy, const mjv_bf16* w,
+                     const int32_t* row_index, int32_t rows, int32_t dim, float eps, void* stream);
+
+/* GQA de-interleave + rotary embedding (modeling_internlm2.py:361-381,233-247):
+ * qkv [rows][kv_heads * (group + 2) * 128] -> q [rows][kv_heads*group*128], k [rows][kv_heads*128], both rotated
+ * with bf16 cos/sin tables [max_pos][128]; V stays in place (read strided by the attention kernel). */
+int mjv_rope_split_bf16(const mjv_bf16* qkv, int64_t ldqkv, mjv_bf16* q, int64_t ldq, mjv_bf16* k, int64_t ldk,
+                        const mjv_bf16* cos_tab, const mjv_bf16* sin_tab, const int32_t* positions,
+                        int32_t rows, int32_t kv_heads, int32_t group, void* stream);
+
+/* im2col for the patch-embedding conv (modeling_intern_vit.py:145-147,164): pixels [tiles][3][S][S] ->
+ * patches [tiles * (S/P)^2][ldp], column = c*P*P + i*P + j, zero-padded to ldp. */
+int mjv_patchify_bf16(const mjv_bf16* pixels, mjv_bf16* patches, int64_t ldp, int32_t tiles, int32_t image_size,
+                      int32_t patch, void* stream);
+
+/* CLS row of every tile: x[tile * tokens_per_tile] = bf16(cls + pos0)   (modeling_intern_vit.py:166-173) */
+int mjv_cls_rows_bf16(mjv_bf16* x, int64_t ldx, const mjv_bf16* cls, const mjv_bf16* pos0, int32_t tiles,
+                      int32_t tokens_per_tile, int32_t dim, void* stream);
+
+/* tok_embeddings gather (modeling_internvl_chat.py:163): x[t] = table[ids[t]] unless ids[t] == skip_id
+ * (those rows are written by the projector GEMM through out_rows). */
+int mjv_embed_gather_bf16(const int32_t* ids, const mjv_bf16* table, int64_t ldt, mjv_bf16* x, int64_t ldx,
+                          int32_t rows, int32_t dim, int32_t skip_id, int32_t vocab, void* stream);
+
+/* Reward / gating heads (moe_reward.py:226-285).  hn = post-final-norm rows: [0,B) reward rows h_r,
+ * [B,2B) gating rows h_g.  ga/gc = outputs of the last hidden layer (post-ReLU) of the aspect / criteria
+ * gating MLPs.  Outputs follow CustomOutput (moe_reward.py:287-297). */
+typedef struct mjv_heads_desc {
+  const mjv_bf16* hn; int64_t ldh; int32_t hidden;
+  const mjv_bf16* ga; const mjv_bf16* gc; int64_t ldg; int32_t gate_hidden;
+  const mjv_bf16* w_reg;      /* [n_obj][hidden]  regression_layer.weight */
+  const mjv_bf16* w_transform;/* [n_obj][n_obj]   reward_transform_matrix */
+  const mjv_bf16* wa; const mjv_bf16* ba;  /* aspect_gating last layer   [n_asp][gate_hidden], [n_asp] */
+  const mjv_bf16* wc; const mjv_bf16* bc;  /* criteria_gating last layer [n_obj][gate_hidden], [n_obj] */
+  const mjv_bf16* ls_a; const mjv_bf16* ls_c; /* logit_scale[0] of each net */
+  float temperature;
+  int32_t batch, n_obj, n_asp;
+  const int32_t* group_offsets; /* [n_asp + 1] into group_index */
+  const int32_t* group_index;   /* [n_obj] criteria ids in aspect2criteria dict order */
+  mjv_bf16* rewards;            /* [B][n_obj] */
+  mjv_bf16* criteria_gating;    /* [B][n_obj] pre-softmax */
+  mjv_bf16* aspect_gating;      /* [B][n_asp] */
+  mjv_bf16* aspect_weights;     /* [B][n_obj] concatenated in dict order */
+  mjv_bf16* weighted_last;      /* [B] last aspect's bf16 weighted sum (moe_reward.py:273,294) */
+  float* aspect_scores;         /* [B][n_asp] */
+  float* score;                 /* [B] */
+  float* packed34;              /* optional [B][1 + n_asp + n_obj] = (score, aspect_scores, rewards) for the
+                                   RCCL all-gather of SURVEY.md §8(e); may be NULL */
+} mjv_heads_desc;
+
+int mjv_reward_heads_bf16(const mjv_heads_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Opt-in profiler: when enabled, every launch is bracketed by hipEvents recorded on ITS stream.
+ * mjv_prof_collect synchronises those events and accumulates per-kernel-tag time; used by bench.py
+ * for the roofline line (kernel average launch duration measured on the launch stream).
+ * ------------------------------------------------------------------------------------------- */
+int mjv_prof_enable(int32_t on);
+int mjv_prof_reset(void);
+int mjv_prof_collect(void);
+/* number of distinct tags seen; tag i: name, launches, total ms, total algorithmic flops, total algorithmic bytes */
+int mjv_prof_count(void);
+int mjv_prof_get(int32_t i, const char** name, int64_t* launches, double* ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJV_H_ */

@@ -1,0 +1,241 @@
+// Flash-style attention for gfx950 over packed variable-length sequences.
+//
+// One workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries.  K/V tiles of
+// 64 keys are staged through LDS (register staged, padded pitches: K rows are read row-wise with
+// ds_read_b128, V rows column-wise with ds_read_b64_tr_b16).
+//
+// QK^T is computed SWAPPED, S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows, B = Q^T), so a lane
+// owns ONE query (MFMA column) and its 16 accumulator registers are 16 keys: row max / row sum are
+// in-register plus one cross-half exchange.  The exponentiated tile is converted to bf16 in place and
+// used directly as the B operand of the second product O^T = V^T P^T (cdna_hip_programming.md §3
+// "An accumulator tile as the next MFMA's operand"): O^T keeps the query on the lane, so the online
+// softmax rescale is a per-lane scalar multiply.
+#include "mjv_common.h"
+
+namespace {
+
+struct AttnArgs {
+  const u16 *Q, *K, *V;
+  u16* O;
+  long ldq, ldk, ldv, ldo;
+  int qhs, khs, vhs, ohs;
+  const int* cu;
+  int n_heads, kv_group;
+  int causal;
+  float scale;
+  int round_mode;
+};
+
+constexpr int QB = 128;  // queries per workgroup
+constexpr int KB = 64;   // keys per tile
+
+template <int D>
+struct Cfg {
+  static constexpr int KP = D * 2 + 16;                 // K row pitch (bytes): odd number of 16-B slots
+  static constexpr int VP = (D == 64) ? 192 : 320;      // V row pitch: 64 * odd, so 4 rows tile the 64 banks
+  static constexpr int K_BYTES = KB * KP;
+  static constexpr int V_BYTES = KB * VP;
+  static constexpr int CHUNKS = D / 8;                  // 16-B chunks per row
+  static constexpr int LOADS = KB * CHUNKS / 256;       // chunks per thread per tile
+};
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
+  using C = Cfg<D>;
+  __shared__ __attribute__((aligned(16))) char smem[C::K_BYTES + C::V_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + C::K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int seq = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+  const int s0 = p.cu[seq];
+  const int len = p.cu[seq + 1] - s0;
+  if (qb * QB >= len) return;
+  const int kvh = head / p.kv_group;
+
+  const int q0 = qb * QB + wave * 32;
+  const int qi = q0 + l31;                 // query index within the sequence
+  const int qrow = s0 + (qi < len ? qi : len - 1);
+
+  // Q fragments: B operand, lane holds Q[query l31][d = 16*ks + 8*hi + j]
+  bf16x8 qf[D / 16];
+  {
+    const u16* qp = p.Q + (long)qrow * p.ldq + (long)head * p.qhs + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  f32x16 oacc[D / 32];
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int kv_end = CAUSAL ? min(len, (qb + 1) * QB) : len;
+  const int n_tiles = (kv_end + KB - 1) / KB;
+  const u16* Kg = p.K + (long)kvh * p.khs;
+  const u16* Vg = p.V + (long)kvh * p.vhs;
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    // ---- stage K/V tile (global -> registers -> LDS)
+    u32x4 kreg[C::LOADS], vreg[C::LOADS];
+#pragma unroll
+    for (int c = 0; c < C::LOADS; ++c) {
+      const int idx = tid + c * 256;
+      const int row = idx / C::CHUNKS, ch = idx % C::CHUNKS;
+      int kr = kt * KB + row;
+      kr = kr < len ? kr : len - 1;
+      kreg[c] = *(const u32x4*)(Kg + (long)(s0 + kr) * p.ldk + ch * 8);
+      vreg[c] = *(const u32x4*)(Vg + (long)(s0 + kr) * p.ldv + ch * 8);
+    }
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int c = 0; c < C::LOADS; ++c) {
+      const int idx = tid + c * 256;
+      const int row = idx / C::CHUNKS, ch = idx % C::CHUNKS;
+      *(u32x4*)(Ks + row * C::KP + ch * 16) = kreg[c];
+      *(u32x4*)(Vs + row * C::VP + ch * 16) = vreg[c];
+    }
+    __syncthreads();
+
+    const int k0 = kt * KB;
+    if (CAUSAL && k0 > q0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles
+    f32x16 sacc[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[t2][r] = 0.f;
+      const char* kp = Ks + (t2 * 32 + l31) * C::KP + hi * 16;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kp + ks * 32);
+        sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t2], 0, 0, 0);
+      }
+    }
+
+    // ---- scores with the reference's rounding, masking, online softmax
+    const bool need_mask = (k0 + KB > len) || (CAUSAL && (k0 + KB - 1 > q0));
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = sacc[t2][r];
+        s = p.round_mode ? rbf(rbf(s) * p.scale) : rbf(s * p.scale);
+        if (need_mask) {
+          const int key = k0 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= len || (CAUSAL && key > qi)) s = -INFINITY;
+        }
+        sacc[t2][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f((m_run - m_new) * LOG2E);
+    const float mb = m_new * LOG2E;
+    float psum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = exp2f(sacc[t2][r] * LOG2E - mb);
+        psum += pv[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4 w = pack8(pv + 8 * s2);
+        pf[t2][s2] = __builtin_bit_cast(bf16x8, w);
+      }
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+    // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads.
+    // element j of the fragment <-> key 32*t2 + 16*s2 + 8*(j>>2) + 4*hi + (j&3)
+    {
+      const int g16 = (lane >> 4) & 1;     // which 16-column block of the 32-wide d tile
+      const int li = lane & 15;
+      const int trow = li >> 2, tcol = 4 * (li & 3);
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int kbase = t2 * 32 + s2 * 16 + 4 * hi + trow;
+            const char* vp = Vs + kbase * C::VP + (dt * 32 + g16 * 16 + tcol) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+            const s16x4 hi4 =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * C::VP));
+            s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf[t2][s2], oacc[dt], 0, 0, 0);
+          }
+      }
+    }
+  }
+
+  // ---- epilogue: O[query][d] = O^T / l ; lane = query, register r <-> d = 32*dt + (r&3) + 8*(r>>2) + 4*hi
+  if (qi < len) {
+    const float inv = 1.0f / l_run;
+    u16* op = p.O + (long)(s0 + qi) * p.ldo + (long)head * p.ohs;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 v = {pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
+                   pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv)};
+        *(u32x2*)(op + dt * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+template <int D, bool CAUSAL>
+int launch(const AttnArgs& a, int n_seqs, int max_seqlen, hipStream_t s) {
+  dim3 grid((max_seqlen + QB - 1) / QB, a.n_heads, n_seqs);
+  hipLaunchKernelGGL((attn_kernel<D, CAUSAL>), grid, dim3(256), 0, s, a);
+  return mjv_check_launch("attention");
+}
+
+}  // namespace
+
+extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
+  MJV_REQUIRE(d && d->Q && d->K && d->V && d->O && d->cu_seqlens, "attention: null pointer");
+  MJV_REQUIRE(d->head_dim == 64 || d->head_dim == 128, "attention: head_dim %d not in {64,128}", d->head_dim);
+  MJV_REQUIRE(d->n_seqs > 0 && d->max_seqlen > 0 && d->n_heads > 0 && d->kv_group > 0, "attention: bad sizes");
+  MJV_REQUIRE(d->n_heads % d->kv_group == 0, "attention: n_heads %% kv_group != 0");
+  MJV_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "attention: ld alignment");
+  MJV_REQUIRE(d->q_head_stride % 8 == 0 && d->k_head_stride % 8 == 0 && d->v_head_stride % 8 == 0 &&
+                  d->o_head_stride % 4 == 0, "attention: head stride alignment");
+  MJV_REQUIRE(((uintptr_t)d->Q | (uintptr_t)d->K | (uintptr_t)d->V) % 16 == 0 && (uintptr_t)d->O % 8 == 0,
+              "attention: misaligned pointer");
+  AttnArgs a;
+  a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
+  a.qhs = d->q_head_stride; a.khs = d->k_head_stride; a.vhs = d->v_head_stride; a.ohs = d->o_head_stride;
+  a.cu = d->cu_seqlens; a.n_heads = d->n_heads; a.kv_group = d->kv_group; a.causal = d->causal;
+  a.scale = d->scale; a.round_mode = d->score_round_mode;
+  hipStream_t s = (hipStream_t)stream;
+  // algorithmic flops: 4 * D per (query, key) pair, halved under the causal mask (upper bound via max_seqlen)
+  const double pairs = (double)d->n_seqs * d->n_heads * (double)d->max_seqlen * d->max_seqlen * (d->causal ? 0.5 : 1.0);
+  const double flops = 4.0 * d->head_dim * pairs;
+  if (d->head_dim == 64) {
+    if (d->causal) { MjvProfScope ps("attn_d64_causal", s, flops, 0); return launch<64, true>(a, d->n_seqs, d->max_seqlen, s); }
+    MjvProfScope ps("attn_d64", s, flops, 0);
+    return launch<64, false>(a, d->n_seqs, d->max_seqlen, s);
+  }
+  if (d->causal) { MjvProfScope ps("attn_d128_causal", s, flops, 0); return launch<128, true>(a, d->n_seqs, d->max_seqlen, s); }
+  MjvProfScope ps("attn_d128", s, flops, 0);
+  return launch<128, false>(a, d->n_seqs, d->max_seqlen, s);
+}

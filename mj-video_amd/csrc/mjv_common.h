@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 kernels of libmjv_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "mjv.h"
+
+typedef uint16_t u16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define MJV_DEV __device__ __forceinline__
+
+// bf16 <-> f32.  The plain cast lowers to v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-preserving).
+MJV_DEV float bf2f(u16 u) { return __uint_as_float(((unsigned)u) << 16); }
+MJV_DEV u16 f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(u16, b);
+}
+// round an fp32 value through bf16 (a torch op boundary in the reference's bf16 path)
+MJV_DEV float rbf(float f) { return bf2f(f2bf(f)); }
+MJV_DEV unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+MJV_DEV void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+MJV_DEV u32x4 pack8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+MJV_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+MJV_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host side -------------------------------------------------------------------------------
+void mjv_set_error(const char* fmt, ...);
+int mjv_check_launch(const char* what);
+
+// profiler hooks (capi.cpp)
+struct MjvProfScope {
+  MjvProfScope(const char* tag, hipStream_t s, double flops, double bytes);
+  ~MjvProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
+#define MJV_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      mjv_set_error(__VA_ARGS__);         \
+      return MJV_E_ARG;                   \
+    }                                     \
+  } while (0)

@@ -1,0 +1,648 @@
+"""Host-side mirror of the reference's reward model, running on the gfx950 kernels of libmjv_hip.so.
+
+``InternVLChatRewardModeling`` keeps the reference's class API (scripts/model/moe_reward.py:137-297):
+same constructor, same attributes callers touch (``.model.img_context_token_id``, ``.model.device``,
+``.config.pad_token_id``, ``.regression_layer`` ...), same ``forward`` signature and ``CustomOutput``
+fields, same checkpoint key layout (``load_state_dict(strict=True)`` of an MJ-VIDEO checkpoint works).
+The nn.Modules below only HOLD parameters under the reference's names; ``forward`` never calls a
+torch op on them - every computation is a C-ABI call (mj_video_amd.ops).  There is no CPU path:
+without the HIP library or a GPU the forward raises.
+
+Differences that are deliberate, all output-preserving:
+  * right-padded batches are packed (pad rows are never computed; the reference proves
+    padded-batch == per-sample results);
+  * the LM head GEMM and the 25 retained hidden states are skipped (their results are unused);
+  * attention never materialises N x N scores.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass, fields
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_SCALE_RES, EPI_SILU_MUL, HeadsDesc)
+from .chat_input import get_conv_template
+from .configuration import InternVLChatConfig, InternVLChatRewardModelingConfig
+
+BF16 = torch.bfloat16
+
+# `<|im_end|><|im_start|>assistant\n` in InternLM2 token ids (moe_reward.py:45-48)
+token_pattern = [92542, 92543, 525, 11353, 364]
+
+
+def find_token_for_gating(lst) -> int:
+    """Index of the LAST occurrence of ``token_pattern`` in ``lst`` (moe_reward.py:50-57)."""
+    a = np.asarray(lst)
+    n = len(token_pattern)
+    if a.shape[0] >= n:
+        hit = np.ones(a.shape[0] - n + 1, dtype=bool)
+        for j, t in enumerate(token_pattern):
+            hit &= a[j:a.shape[0] - n + 1 + j] == t
+        idx = np.flatnonzero(hit)
+        if idx.size:
+            return int(idx[-1])
+    raise ValueError("Token pattern not found in the list.")
+
+
+@dataclass
+class CustomOutput:
+    """Field-for-field mirror of moe_reward.py:60-89 (attribute, key and index access like HF ModelOutput)."""
+    rewards: Optional[torch.Tensor] = None
+    hidden_state: Optional[torch.Tensor] = None
+    prompt_embedding: Optional[torch.Tensor] = None
+    criteria_gating_output: Optional[torch.Tensor] = None
+    aspect_gating_output: Optional[torch.Tensor] = None
+    aspect_weights: Optional[torch.Tensor] = None
+    score: Optional[torch.Tensor] = None
+    weighted_scores: Optional[torch.Tensor] = None
+    aspect_scores: Optional[torch.Tensor] = None
+
+    def to_tuple(self):
+        return tuple(getattr(self, f.name) for f in fields(self) if getattr(self, f.name) is not None)
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else self.to_tuple()[k]
+
+    def keys(self):
+        return [f.name for f in fields(self) if getattr(self, f.name) is not None]
+
+
+# ------------------------------------------------------------------------------- parameter holders
+class _Linear(nn.Module):
+    def __init__(self, fin: int, fout: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = fin, fout
+        self.weight = nn.Parameter(torch.empty(fout, fin), requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(fout), requires_grad=False)
+        else:
+            self.register_parameter("bias", None)
+
+
+class _Norm(nn.Module):
+    def __init__(self, dim: int, bias: bool, eps: float):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim), requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(dim), requires_grad=False)
+
+
+class _Act(nn.Module):  # index placeholder so mlp1 keeps the reference's 0/1/3 numbering
+    pass
+
+
+class _PatchEmbedding(nn.Module):
+    def __init__(self, dim: int, patch: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(dim, 3, patch, patch), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(dim), requires_grad=False)
+
+
+class _VisionEmbeddings(nn.Module):
+    def __init__(self, vc):
+        super().__init__()
+        npos = (vc.image_size // vc.patch_size) ** 2 + 1
+        self.class_embedding = nn.Parameter(torch.empty(1, 1, vc.hidden_size), requires_grad=False)
+        self.position_embedding = nn.Parameter(torch.empty(1, npos, vc.hidden_size), requires_grad=False)
+        self.patch_embedding = _PatchEmbedding(vc.hidden_size, vc.patch_size)
+
+
+class _VisionAttention(nn.Module):
+    def __init__(self, vc):
+        super().__init__()
+        self.qkv = _Linear(vc.hidden_size, 3 * vc.hidden_size, bias=vc.qkv_bias)
+        self.proj = _Linear(vc.hidden_size, vc.hidden_size)
+
+
+class _VisionMLP(nn.Module):
+    def __init__(self, vc):
+        super().__init__()
+        self.fc1 = _Linear(vc.hidden_size, vc.intermediate_size)
+        self.fc2 = _Linear(vc.intermediate_size, vc.hidden_size)
+
+
+class _VisionLayer(nn.Module):
+    def __init__(self, vc):
+        super().__init__()
+        d = vc.hidden_size
+        self.ls1 = nn.Parameter(torch.ones(d), requires_grad=False)
+        self.ls2 = nn.Parameter(torch.ones(d), requires_grad=False)
+        self.attn = _VisionAttention(vc)
+        self.mlp = _VisionMLP(vc)
+        self.norm1 = _Norm(d, True, vc.layer_norm_eps)
+        self.norm2 = _Norm(d, True, vc.layer_norm_eps)
+
+
+class _VisionEncoder(nn.Module):
+    def __init__(self, vc):
+        super().__init__()
+        self.layers = nn.ModuleList([_VisionLayer(vc) for _ in range(vc.num_hidden_layers)])
+
+
+class InternVisionModel(nn.Module):
+    """Parameter layout of internvl2/modeling_intern_vit.py:364-430."""
+
+    def __init__(self, vc):
+        super().__init__()
+        if vc.norm_type != "layer_norm" or vc.qk_normalization:
+            raise NotImplementedError("only the layer_norm / no-qk-norm InternViT (InternVL2-2B tower) is built")
+        if vc.hidden_size // vc.num_attention_heads != 64:
+            raise NotImplementedError("ViT attention kernel is specialised on head_dim 64")
+        self.config = vc
+        self.embeddings = _VisionEmbeddings(vc)
+        self.encoder = _VisionEncoder(vc)
+
+
+class _LMAttention(nn.Module):
+    def __init__(self, lc):
+        super().__init__()
+        hd = lc.hidden_size // lc.num_attention_heads
+        self.wqkv = _Linear(lc.hidden_size, (lc.num_attention_heads + 2 * lc.num_key_value_heads) * hd, bias=lc.bias)
+        self.wo = _Linear(lc.num_attention_heads * hd, lc.hidden_size, bias=lc.bias)
+
+
+class _LMFeedForward(nn.Module):
+    def __init__(self, lc):
+        super().__init__()
+        self.w1 = _Linear(lc.hidden_size, lc.intermediate_size, bias=False)
+        self.w3 = _Linear(lc.hidden_size, lc.intermediate_size, bias=False)
+        self.w2 = _Linear(lc.intermediate_size, lc.hidden_size, bias=False)
+
+
+class _LMLayer(nn.Module):
+    def __init__(self, lc):
+        super().__init__()
+        self.attention = _LMAttention(lc)
+        self.feed_forward = _LMFeedForward(lc)
+        self.attention_norm = _Norm(lc.hidden_size, False, lc.rms_norm_eps)
+        self.ffn_norm = _Norm(lc.hidden_size, False, lc.rms_norm_eps)
+
+
+class _Embedding(nn.Module):
+    def __init__(self, n: int, d: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, d), requires_grad=False)
+
+
+class InternLM2Model(nn.Module):
+    def __init__(self, lc):
+        super().__init__()
+        self.tok_embeddings = _Embedding(lc.vocab_size, lc.hidden_size)
+        self.layers = nn.ModuleList([_LMLayer(lc) for _ in range(lc.num_hidden_layers)])
+        self.norm = _Norm(lc.hidden_size, False, lc.rms_norm_eps)
+
+
+class InternLM2ForCausalLM(nn.Module):
+    """Parameter layout of internvl2/modeling_internlm2.py:987-1000 (``output`` is loaded, never used)."""
+
+    def __init__(self, lc):
+        super().__init__()
+        if lc.bias:
+            raise NotImplementedError("InternLM2 with attention biases is not built (MJ-VIDEO-2B has bias=False)")
+        if lc.hidden_size // lc.num_attention_heads != 128:
+            raise NotImplementedError("LLM attention kernel is specialised on head_dim 128")
+        self.config = lc
+        self.model = InternLM2Model(lc)
+        self.output = _Linear(lc.hidden_size, lc.vocab_size, bias=False)
+
+    def get_input_embeddings(self):
+        return self.model.tok_embeddings
+
+
+class InternVLChatModel(nn.Module):
+    """Parameter layout + attributes of internvl2/modeling_internvl_chat.py:100-144."""
+
+    def __init__(self, config: InternVLChatConfig):
+        super().__init__()
+        self.config = config
+        image_size = config.force_image_size or config.vision_config.image_size
+        self.patch_size = config.vision_config.patch_size
+        self.select_layer = config.select_layer
+        self.template = config.template
+        self.downsample_ratio = config.downsample_ratio
+        self.ps_version = config.ps_version
+        self.num_image_token = int((image_size // self.patch_size) ** 2 * (config.downsample_ratio ** 2))
+        if config.select_layer != -1:
+            raise NotImplementedError("select_layer != -1 is not built (MJ-VIDEO-2B uses the last ViT layer)")
+        if config.ps_version == "v1" or config.downsample_ratio != 0.5:
+            raise NotImplementedError("only pixel-shuffle v2 with downsample_ratio 0.5 is built")
+        self.vision_model = InternVisionModel(config.vision_config)
+        self.language_model = InternLM2ForCausalLM(config.llm_config)
+        vit_hidden, llm_hidden = config.vision_config.hidden_size, config.llm_config.hidden_size
+        c4 = vit_hidden * int(1 / self.downsample_ratio) ** 2
+        self.mlp1 = nn.Sequential(_Norm(c4, True, 1e-5), _Linear(c4, llm_hidden), _Act(), _Linear(llm_hidden, llm_hidden))
+        self.img_context_token_id = None
+        self.conv_template = get_conv_template(self.template) if self.template else None
+        self.system_message = self.conv_template.system_message if self.conv_template else None
+
+    @property
+    def device(self):
+        return self.mlp1[1].weight.device
+
+    @property
+    def dtype(self):
+        return self.mlp1[1].weight.dtype
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, config: Optional[InternVLChatConfig] = None, **kwargs):
+        """Builds the model from ``config.json`` in a local directory and loads ``*.safetensors`` next to it
+        when present (no hub access exists here; the reference's HF call is modeling_internvl_chat.py / moe_reward.py:142)."""
+        if config is None:
+            config = InternVLChatConfig.from_pretrained(name_or_path)
+        model = cls(config)
+        if isinstance(name_or_path, str) and os.path.isdir(name_or_path):
+            files = sorted(f for f in os.listdir(name_or_path) if f.endswith(".safetensors"))
+            if files:
+                from safetensors.torch import load_file
+                sd = {}
+                for f in files:
+                    sd.update(load_file(os.path.join(name_or_path, f)))
+                model.load_state_dict(sd, strict=True)
+        return model
+
+
+class GatingNetwork(nn.Module):
+    """Parameter layout of moe_reward.py:16-42."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, temperature: float = 10,
+                 logit_scale: float = 1., hidden_dim: int = 1024, n_hidden: int = 3):
+        super().__init__()
+        self.temperature = temperature
+        self.logit_scale = nn.Parameter(torch.ones(1) * logit_scale, requires_grad=False)
+        layers = []
+        for _ in range(n_hidden):
+            layers.append(_Linear(in_features, hidden_dim))
+            in_features = hidden_dim
+        layers.append(_Linear(in_features, out_features, bias=bias))
+        self.layers = nn.ModuleList(layers)
+
+
+# ------------------------------------------------------------------------------------ the reward model
+class InternVLChatRewardModeling(nn.Module):
+    def __init__(self, name: str, config, base_model: Optional[InternVLChatModel] = None):
+        super().__init__()
+        self.num_labels = getattr(config, "num_labels", 2)
+        self.model = base_model if base_model is not None else InternVLChatModel.from_pretrained(name, config=config)
+        config_dict = config.to_dict()
+        self.num_objectives = config_dict["num_objectives"]
+        self.num_aspects = config_dict["num_aspects"]
+        self.aspect2criteria = {k: list(v) for k, v in config_dict["aspect2criteria"].items()}
+        # sanity checks of moe_reward.py:153-157
+        assert len(self.aspect2criteria) == self.num_aspects
+        assert sum(len(v) for v in self.aspect2criteria.values()) == self.num_objectives
+        temp = []
+        for k in self.aspect2criteria.values():
+            temp += k
+        assert sum(len(set(v)) for v in self.aspect2criteria.values()) == len(set(temp))
+
+        hidden_size = config.llm_config.hidden_size
+        self.regression_layer = _Linear(hidden_size, self.num_objectives, bias=False)
+        self.reward_transform_matrix = nn.Parameter(torch.eye(self.num_objectives), requires_grad=False)
+        self.aspect_gating = GatingNetwork(hidden_size, self.num_aspects, temperature=config_dict["gating_temperature"],
+                                           hidden_dim=config_dict["gating_hidden_dim"],
+                                           n_hidden=config_dict["gating_n_hidden"])
+        self.criteria_gating = GatingNetwork(hidden_size, config.num_objectives,
+                                             temperature=config_dict["gating_temperature"],
+                                             hidden_dim=config_dict["gating_hidden_dim"],
+                                             n_hidden=config_dict["gating_n_hidden"])
+        self.config = config
+        self._derived: Dict[str, object] = {}
+        self._derived_sig = None
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._rope: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.last_packed34: Optional[torch.Tensor] = None
+        self.debug_probes: Optional[Dict[str, torch.Tensor]] = None  # tests set {} to capture per-layer states
+
+    # -- construction helpers -------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config, dtype=torch.float32) -> "InternVLChatRewardModeling":
+        """Uninitialised parameters of the right shapes in ``dtype`` (fill with ``load_state_dict``)."""
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            return cls("<config>", config, base_model=InternVLChatModel(config))
+        finally:
+            torch.set_default_dtype(prev)
+
+    # -- derived (pre-arranged) weights ----------------------------------------------------------
+    def _signature(self):
+        ps = list(self.parameters())
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
+
+    def _prepare(self, device):
+        """One-time weight layout conversion (redone if any parameter storage/version changed):
+        K-padded patch-embedding matrix, 16-row interleaved w1|w3, head index tables."""
+        sig = self._signature()
+        if self._derived_sig == sig:
+            return self._derived
+        for p in self.parameters():
+            if p.dtype != BF16:
+                raise TypeError("the HIP path computes in bf16: call model.to(torch.bfloat16) first "
+                                f"(found a {p.dtype} parameter)")
+            if p.device.type != "cuda":
+                raise RuntimeError("the reward model runs on the MI355X only: call model.cuda() first "
+                                   "(there is no CPU path)")
+        d: Dict[str, object] = {}
+        vc, lc = self.config.vision_config, self.config.llm_config
+        emb = self.model.vision_model.embeddings
+        P = vc.patch_size
+        kreal = 3 * P * P
+        kpad = (kreal + 63) // 64 * 64
+        wp = torch.zeros(vc.hidden_size, kpad, dtype=BF16, device=device)
+        wp[:, :kreal] = emb.patch_embedding.weight.reshape(vc.hidden_size, kreal)
+        d["patch_w"], d["patch_k"] = wp, kpad
+        w13 = []
+        for layer in self.model.language_model.model.layers:
+            w1, w3 = layer.feed_forward.w1.weight, layer.feed_forward.w3.weight
+            ff, h = w1.shape
+            if ff % 16:
+                raise NotImplementedError("intermediate_size must be a multiple of 16")
+            w13.append(torch.stack([w1.view(ff // 16, 16, h), w3.view(ff // 16, 16, h)], dim=1).reshape(2 * ff, h).contiguous())
+        d["w13"] = w13
+        offs, idx = [0], []
+        for _, crit in self.aspect2criteria.items():
+            idx += list(crit)
+            offs.append(len(idx))
+        d["group_offsets"] = torch.tensor(offs, dtype=torch.int32, device=device)
+        d["group_index"] = torch.tensor(idx, dtype=torch.int32, device=device)
+        d["pos"] = {}
+        self._derived, self._derived_sig = d, sig
+        return d
+
+    def _pos_table(self, d, grid: int, device) -> torch.Tensor:
+        """[1 + grid*grid, dim] position table; the patch part goes through the fp32 bicubic resample of
+        modeling_intern_vit.py:154-160 when the tile grid differs from the checkpoint's (one-time weight prep;
+        an exact identity at the native grid)."""
+        if grid in d["pos"]:
+            return d["pos"][grid]
+        vc = self.config.vision_config
+        pos = self.model.vision_model.embeddings.position_embedding
+        g0 = vc.image_size // vc.patch_size
+        patch = pos[:, 1:, :]
+        if grid != g0:
+            p = patch.float().reshape(1, g0, g0, -1).permute(0, 3, 1, 2)
+            p = torch.nn.functional.interpolate(p.cpu(), size=(grid, grid), mode="bicubic", align_corners=False)
+            patch = p.reshape(1, -1, grid * grid).permute(0, 2, 1).to(BF16).to(device)
+        table = torch.cat([pos[:, :1, :], patch], dim=1)[0].contiguous()
+        d["pos"][grid] = table
+        return table
+
+    def _rope_tables(self, seq_len: int, device):
+        """bf16 cos/sin tables of modeling_internlm2.py:147-180,204-229 (fp32 math, cast once)."""
+        lc = self.config.llm_config
+        dim = lc.hidden_size // lc.num_attention_heads
+        maxpos = lc.max_position_embeddings
+        n = max(maxpos if seq_len <= maxpos else seq_len, 1)
+        key = (n, str(device))
+        if key in self._rope:
+            return self._rope[key]
+        base = float(lc.rope_theta)
+        rs = lc.rope_scaling
+        if seq_len > maxpos and rs is not None and rs["type"] == "dynamic":
+            base = base * ((rs["factor"] * seq_len / maxpos) - (rs["factor"] - 1)) ** (dim / (dim - 2))
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+        t = torch.arange(n, dtype=inv_freq.dtype)
+        if rs is not None and rs["type"] == "linear":
+            t = t / rs["factor"]
+        freqs = torch.einsum("i,j->ij", t, inv_freq)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        tabs = (emb.cos().to(BF16).to(device).contiguous(), emb.sin().to(BF16).to(device).contiguous())
+        self._rope = {key: tabs}
+        return tabs
+
+    def _buf(self, name: str, rows: int, cols: int, device, dtype=BF16) -> torch.Tensor:
+        t = self._ws.get(name)
+        need = rows * cols
+        if t is None or t.numel() < need or t.device != device or t.dtype != dtype:
+            t = torch.empty(need, dtype=dtype, device=device)
+            self._ws[name] = t
+        return t[:need].view(rows, cols)
+
+    # -- host-side analysis of the token ids (the reference does this with ids.tolist(), moe_reward.py:242)
+    def _analyse_ids(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], n_tiles: int):
+        ids = input_ids.detach().to("cpu").numpy()
+        if ids.ndim != 2:
+            raise ValueError(f"input_ids must be [batch, seq], got {ids.shape}")
+        B, N = ids.shape
+        pad_id = self.config.pad_token_id
+        if pad_id is None and B != 1:
+            raise ValueError("Cannot handle batch sizes > 1 if no padding token is defined.")
+        ctx_id = self.model.img_context_token_id
+        if ctx_id is None:
+            raise ValueError("model.model.img_context_token_id is not set (eval_genai_mjvideo.py:115)")
+        if attention_mask is not None:
+            am = attention_mask.detach().to("cpu").numpy().astype(bool)
+            if am.shape != ids.shape:
+                raise ValueError(f"attention_mask shape {am.shape} != input_ids shape {ids.shape}")
+            lens = am.sum(axis=1)
+            for b in range(B):
+                if not am[b, :lens[b]].all():
+                    raise NotImplementedError("only right-padded attention masks are supported (the reference's "
+                                              "collator and notebook right-pad: dataset.py:445-469)")
+        else:
+            lens = np.full(B, N, dtype=np.int64)
+        if (lens <= 0).any():
+            raise ValueError("empty sequence in the batch")
+        reward_rows, gating_rows, packed, positions, img_rows = [], [], [], [], []
+        cu = [0]
+        for b in range(B):
+            row = ids[b]
+            if pad_id is None:
+                r = N - 1
+            else:
+                r = (int(np.argmax(row == pad_id)) - 1) % N
+            g = find_token_for_gating(row)
+            L = int(lens[b])
+            if r >= L or g >= L:
+                raise ValueError(f"sample {b}: reward row {r} / gating row {g} lies in the masked tail (valid length {L})")
+            base = cu[-1]
+            reward_rows.append(base + r)
+            gating_rows.append(base + g)
+            packed.append(row[:L])
+            positions.append(np.arange(L))
+            img_rows.append(base + np.flatnonzero(row[:L] == ctx_id))
+            if (row[L:] == ctx_id).any():
+                raise ValueError(f"sample {b}: <IMG_CONTEXT> tokens in the masked tail")
+            cu.append(base + L)
+        img_rows = np.concatenate(img_rows)
+        if img_rows.size != n_tiles * self.model.num_image_token:
+            raise ValueError(f"{img_rows.size} <IMG_CONTEXT> tokens in input_ids but pixel_values holds {n_tiles} tiles x "
+                             f"{self.model.num_image_token} image tokens (the reference would silently truncate, "
+                             f"modeling_internvl_chat.py:178-186)")
+        return dict(B=B, N=N, total=cu[-1], max_len=int(lens.max()),
+                    ids=np.concatenate(packed).astype(np.int32), positions=np.concatenate(positions).astype(np.int32),
+                    cu=np.asarray(cu, dtype=np.int32), img_rows=img_rows.astype(np.int32),
+                    sel_rows=np.asarray(reward_rows + gating_rows, dtype=np.int32))
+
+    # -- towers ----------------------------------------------------------------------------------
+    def _vision_tower(self, d, pixel_values: torch.Tensor, hidden: torch.Tensor, img_rows: torch.Tensor):
+        """patchify -> 24 x ViT layer -> pixel-shuffle + mlp1, scattered into the <IMG_CONTEXT> rows of ``hidden``."""
+        dev = pixel_values.device
+        vc = self.config.vision_config
+        vm = self.model.vision_model
+        tiles, _, S, _ = pixel_values.shape
+        P, dim, ff, H = vc.patch_size, vc.hidden_size, vc.intermediate_size, vc.num_attention_heads
+        if S % P or (S // P) % 2:
+            raise ValueError(f"image size {S} must be an even multiple of the patch size {P}")
+        G = S // P
+        npatch, T = G * G, G * G + 1
+        rows = tiles * T
+        pos = self._pos_table(d, G, dev)
+        patches = self._buf("patches", tiles * npatch, d["patch_k"], dev)
+        ops.patchify(pixel_values, patches, P)
+        x = self._buf("vit_x", rows, dim, dev)
+        ops.cls_rows(x, vm.embeddings.class_embedding.view(-1), pos[0], tiles, T)
+        ops.gemm(patches, d["patch_w"], x, EPI_SCALE_RES, bias=vm.embeddings.patch_embedding.bias, res=pos, res_mod=npatch,
+                 res_off=1, out_group=npatch, out_pad=1)
+        probes = self.debug_probes
+        if probes is not None:
+            probes["vit_embed"] = x.clone().view(tiles, T, dim)
+        h = self._buf("vit_h", rows, dim, dev)
+        qkv = self._buf("vit_qkv", rows, 3 * dim, dev)
+        f = self._buf("vit_ff", rows, ff, dev)
+        key = ("vit_cu", tiles, T)
+        cu = self._ws.get(key)
+        if cu is None or cu.device != dev:
+            cu = torch.arange(0, (tiles + 1) * T, T, dtype=torch.int32, device=dev)
+            self._ws[key] = cu
+        scale = (dim // H) ** -0.5
+        for li, layer in enumerate(vm.encoder.layers):
+            ops.layernorm(x, layer.norm1.weight, layer.norm1.bias, h, vc.layer_norm_eps)
+            ops.gemm(h, layer.attn.qkv.weight, qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
+            ops.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], h, cu, T, H, 1, 64, False, scale, 0)
+            ops.gemm(h, layer.attn.proj.weight, x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
+            ops.layernorm(x, layer.norm2.weight, layer.norm2.bias, h, vc.layer_norm_eps)
+            ops.gemm(h, layer.mlp.fc1.weight, f, EPI_BIAS_GELU, bias=layer.mlp.fc1.bias)
+            ops.gemm(f, layer.mlp.fc2.weight, x, EPI_SCALE_RES, bias=layer.mlp.fc2.bias, scale=layer.ls2, res=x)
+            if probes is not None:
+                probes[f"vit_layer{li}"] = x.clone().view(tiles, T, dim)
+        mlp1 = self.model.mlp1
+        ntok = tiles * (G // 2) ** 2
+        pl = self._buf("proj_ln", ntok, 4 * dim, dev)
+        ops.layernorm(x, mlp1[0].weight, mlp1[0].bias, pl, mlp1[0].eps, rows=ntok, gather_grid=G)
+        ph = self._buf("proj_h", ntok, mlp1[1].out_features, dev)
+        ops.gemm(pl, mlp1[1].weight, ph, EPI_BIAS_GELU, bias=mlp1[1].bias)
+        ops.gemm(ph, mlp1[3].weight, hidden, EPI_BIAS, bias=mlp1[3].bias, out_rows=img_rows)
+        if probes is not None:
+            probes["vit_embeds"] = hidden[img_rows.long()].clone().view(tiles, -1, hidden.shape[1])
+        return x
+
+    def _language_tower(self, d, x: torch.Tensor, cu: torch.Tensor, positions: torch.Tensor, max_len: int):
+        dev = x.device
+        lc = self.config.llm_config
+        lm = self.model.language_model.model
+        H, KV = lc.num_attention_heads, lc.num_key_value_heads
+        G = H // KV
+        hd = 128
+        n, hdim = x.shape
+        ff = lc.intermediate_size
+        cos, sin = self._rope_tables(max_len, dev)
+        hn = self._buf("llm_hn", n, hdim, dev)
+        qkv = self._buf("llm_qkv", n, (H + 2 * KV) * hd, dev)
+        q = self._buf("llm_q", n, H * hd, dev)
+        k = self._buf("llm_k", n, KV * hd, dev)
+        act = self._buf("llm_act", n, ff, dev)
+        scale = 1.0 / math.sqrt(hd)
+        v_view = qkv[:, (G + 1) * hd:]
+        for li, layer in enumerate(lm.layers):
+            ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
+            ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_BIAS)
+            ops.rope_split(qkv, q, k, cos, sin, positions, KV, G)
+            ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, 1, v_head_stride=(G + 2) * hd)
+            ops.gemm(hn, layer.attention.wo.weight, x, EPI_SCALE_RES, res=x)
+            ops.rmsnorm(x, layer.ffn_norm.weight, hn, lc.rms_norm_eps)
+            ops.gemm(hn, d["w13"][li], act, EPI_SILU_MUL)
+            ops.gemm(act, layer.feed_forward.w2.weight, x, EPI_SCALE_RES, res=x)
+            if self.debug_probes is not None:
+                self.debug_probes[f"llm_layer{li}"] = x.clone()
+        return x
+
+    # -- forward ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, pixel_values: torch.Tensor, input_ids: torch.Tensor = None,
+                attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
+                image_flags: Optional[torch.Tensor] = None, past_key_values=None, labels=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None) -> CustomOutput:
+        if input_ids is None:
+            raise ValueError("input_ids is required (the reward heads locate their rows from the token ids)")
+        if position_ids is not None or past_key_values is not None or labels is not None:
+            raise NotImplementedError("position_ids / past_key_values / labels are not part of the scoring path")
+        if pixel_values.dim() != 4:
+            raise ValueError(f"wrong pixel_values size: {tuple(pixel_values.shape)}")
+        dev = self.model.device
+        if dev.type != "cuda":
+            raise RuntimeError("InternVLChatRewardModeling.forward runs on the MI355X only: move the model with .cuda()")
+        d = self._prepare(dev)
+        if pixel_values.dtype != BF16:
+            raise TypeError(f"pixel_values must be bfloat16 like the model (got {pixel_values.dtype}); "
+                            "callers cast with .to(torch.bfloat16) (eval_genai_mjvideo.py:131)")
+        pixel_values = pixel_values.to(dev).contiguous()
+        info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])
+        B, total = info["B"], info["total"]
+        lc = self.config.llm_config
+        hdim = lc.hidden_size
+
+        def up(a):
+            return torch.from_numpy(a).to(dev, non_blocking=True)
+
+        ids, positions, cu = up(info["ids"]), up(info["positions"]), up(info["cu"])
+        img_rows, sel_rows = up(info["img_rows"]), up(info["sel_rows"])
+
+        hidden = self._buf("llm_x", total, hdim, dev)
+        ops.embed_gather(ids, self.model.language_model.model.tok_embeddings.weight, hidden, self.model.img_context_token_id)
+        self._vision_tower(d, pixel_values, hidden, img_rows)
+        if self.debug_probes is not None:
+            self.debug_probes["llm_embed"] = hidden.clone()
+        self._language_tower(d, hidden, cu, positions, info["max_len"])
+
+        # final RMSNorm only on the 2 rows per sample the heads read (hidden_states[-1] is post-norm, moe_reward.py:211)
+        sel = torch.empty(2 * B, hdim, dtype=BF16, device=dev)
+        ops.rmsnorm(hidden, self.model.language_model.model.norm.weight, sel, lc.rms_norm_eps, row_index=sel_rows)
+        h_g = sel[B:]
+        gh = self.aspect_gating.layers[0].out_features
+
+        def gating_hidden(net: GatingNetwork, tag: str) -> torch.Tensor:
+            cur = h_g
+            for j, layer in enumerate(net.layers[:-1]):
+                out = self._buf(f"gate_{tag}{j & 1}", B, layer.out_features, dev)
+                ops.gemm(cur, layer.weight, out, EPI_BIAS_RELU, bias=layer.bias)
+                cur = out
+            return cur
+
+        ga = gating_hidden(self.aspect_gating, "a")
+        gc = gating_hidden(self.criteria_gating, "c")
+        nobj, nasp = self.num_objectives, self.num_aspects
+        rewards = torch.empty(B, nobj, dtype=BF16, device=dev)
+        crit = torch.empty(B, nobj, dtype=BF16, device=dev)
+        asp_gate = torch.empty(B, nasp, dtype=BF16, device=dev)
+        asp_w = torch.empty(B, nobj, dtype=BF16, device=dev)
+        weighted = torch.empty(B, dtype=BF16, device=dev)
+        asp_scores = torch.empty(B, nasp, dtype=torch.float32, device=dev)
+        score = torch.empty(B, dtype=torch.float32, device=dev)
+        packed = torch.empty(B, 1 + nasp + nobj, dtype=torch.float32, device=dev)
+        hd = HeadsDesc()
+        hd.hn, hd.ldh, hd.hidden = sel.data_ptr(), sel.stride(0), hdim
+        hd.ga, hd.gc, hd.ldg, hd.gate_hidden = ga.data_ptr(), gc.data_ptr(), ga.stride(0), gh
+        hd.w_reg = self.regression_layer.weight.data_ptr()
+        hd.w_transform = self.reward_transform_matrix.data_ptr()
+        la, lcg = self.aspect_gating.layers[-1], self.criteria_gating.layers[-1]
+        hd.wa, hd.ba, hd.wc, hd.bc = la.weight.data_ptr(), la.bias.data_ptr(), lcg.weight.data_ptr(), lcg.bias.data_ptr()
+        hd.ls_a, hd.ls_c = self.aspect_gating.logit_scale.data_ptr(), self.criteria_gating.logit_scale.data_ptr()
+        hd.temperature = float(self.criteria_gating.temperature)
+        hd.batch, hd.n_obj, hd.n_asp = B, nobj, nasp
+        hd.group_offsets, hd.group_index = d["group_offsets"].data_ptr(), d["group_index"].data_ptr()
+        hd.rewards, hd.criteria_gating, hd.aspect_gating = rewards.data_ptr(), crit.data_ptr(), asp_gate.data_ptr()
+        hd.aspect_weights, hd.weighted_last = asp_w.data_ptr(), weighted.data_ptr()
+        hd.aspect_scores, hd.score, hd.packed34 = asp_scores.data_ptr(), score.data_ptr(), packed.data_ptr()
+        ops.reward_heads(hd)
+        self.last_packed34 = packed
+        return CustomOutput(rewards=rewards, hidden_state=sel[:B], prompt_embedding=h_g, criteria_gating_output=crit,
+                            aspect_gating_output=asp_gate, aspect_weights=asp_w, weighted_scores=weighted,
+                            aspect_scores=asp_scores, score=score)

@@ -1,0 +1,166 @@
+"""Thin tensor-level wrappers over the C ABI: torch supplies device memory and the current HIP stream,
+every computation happens in libmjv_hip.so.  All functions enqueue on ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_SCALE_RES, EPI_SILU_MUL, AttnDesc, GemmDesc,
+                   HeadsDesc, check, load_library)
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != BF16 or not t.is_cuda):
+            raise TypeError(f"expected a bf16 device tensor, got {t.dtype} on {t.device}")
+
+
+def _row_stride(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "rows must be contiguous"
+    return t.stride(0)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_BIAS,
+         bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+         res: Optional[torch.Tensor] = None, res_mod: int = 0, res_off: int = 0, out_group: int = 0,
+         out_pad: int = 0, out_rows: Optional[torch.Tensor] = None, M: Optional[int] = None) -> torch.Tensor:
+    """out = epilogue(a[M,K] @ w[N,K]^T); 2-D row-contiguous bf16 views (row strides are honoured)."""
+    _chk_bf16(a, w, out, bias, scale, res)
+    lib = load_library()
+    d = GemmDesc()
+    d.A, d.lda = a.data_ptr(), _row_stride(a)
+    d.W, d.ldw = w.data_ptr(), _row_stride(w)
+    d.C, d.ldc = out.data_ptr(), _row_stride(out)
+    d.M = a.shape[0] if M is None else M
+    d.N, d.K = w.shape[0], w.shape[1]
+    assert a.shape[1] == d.K, (a.shape, w.shape)
+    d.epilogue = epilogue
+    d.bias, d.scale = _p(bias), _p(scale)
+    d.res, d.ldr = _p(res), (_row_stride(res) if res is not None else 0)
+    d.res_mod, d.res_off, d.out_group, d.out_pad = res_mod, res_off, out_group, out_pad
+    if out_rows is not None:
+        assert out_rows.dtype == torch.int32 and out_rows.is_cuda
+    d.out_rows = _p(out_rows)
+    check(lib.mjv_gemm_bf16(C.byref(d), _stream()), "mjv_gemm_bf16")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, cu_seqlens: torch.Tensor,
+              max_seqlen: int, n_heads: int, kv_group: int, head_dim: int, causal: bool, scale: float,
+              score_round_mode: int, q_head_stride: Optional[int] = None, k_head_stride: Optional[int] = None,
+              v_head_stride: Optional[int] = None, o_head_stride: Optional[int] = None) -> torch.Tensor:
+    """q/k/v/out are 2-D views [rows, >= heads*head_dim] (row stride honoured, first head at column 0)."""
+    _chk_bf16(q, k, v, out)
+    assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_cuda
+    lib = load_library()
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.ldq, d.ldk, d.ldv, d.ldo = _row_stride(q), _row_stride(k), _row_stride(v), _row_stride(out)
+    d.q_head_stride = head_dim if q_head_stride is None else q_head_stride
+    d.k_head_stride = head_dim if k_head_stride is None else k_head_stride
+    d.v_head_stride = head_dim if v_head_stride is None else v_head_stride
+    d.o_head_stride = head_dim if o_head_stride is None else o_head_stride
+    d.cu_seqlens = cu_seqlens.data_ptr()
+    d.n_seqs, d.max_seqlen = cu_seqlens.numel() - 1, max_seqlen
+    d.n_heads, d.kv_group, d.head_dim = n_heads, kv_group, head_dim
+    d.causal, d.scale, d.score_round_mode = int(causal), scale, score_round_mode
+    check(lib.mjv_attention_bf16(C.byref(d), _stream()), "mjv_attention_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float,
+              rows: Optional[int] = None, gather_grid: int = 0) -> torch.Tensor:
+    _chk_bf16(x, gamma, beta, out)
+    lib = load_library()
+    rows = out.shape[0] if rows is None else rows
+    check(lib.mjv_layernorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), gamma.data_ptr(),
+                                 beta.data_ptr(), rows, out.shape[1], eps, gather_grid, _stream()),
+          "mjv_layernorm_bf16")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, eps: float,
+            row_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk_bf16(x, w, out)
+    lib = load_library()
+    if row_index is not None:
+        assert row_index.dtype == torch.int32 and row_index.is_cuda
+    check(lib.mjv_rmsnorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), w.data_ptr(),
+                               _p(row_index), out.shape[0], out.shape[1], eps, _stream()), "mjv_rmsnorm_bf16")
+    return out
+
+
+def rope_split(qkv: torch.Tensor, q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+               positions: torch.Tensor, kv_heads: int, group: int) -> None:
+    _chk_bf16(qkv, q, k, cos, sin)
+    assert positions.dtype == torch.int32 and positions.is_cuda
+    assert cos.shape[1] == 128 and cos.is_contiguous() and sin.is_contiguous()
+    lib = load_library()
+    check(lib.mjv_rope_split_bf16(qkv.data_ptr(), _row_stride(qkv), q.data_ptr(), _row_stride(q), k.data_ptr(),
+                                  _row_stride(k), cos.data_ptr(), sin.data_ptr(), positions.data_ptr(),
+                                  qkv.shape[0], kv_heads, group, _stream()), "mjv_rope_split_bf16")
+
+
+def patchify(pixels: torch.Tensor, patches: torch.Tensor, patch: int) -> torch.Tensor:
+    _chk_bf16(pixels, patches)
+    assert pixels.is_contiguous() and pixels.dim() == 4 and pixels.shape[1] == 3 and pixels.shape[2] == pixels.shape[3]
+    lib = load_library()
+    check(lib.mjv_patchify_bf16(pixels.data_ptr(), patches.data_ptr(), _row_stride(patches), pixels.shape[0],
+                                pixels.shape[2], patch, _stream()), "mjv_patchify_bf16")
+    return patches
+
+
+def cls_rows(x: torch.Tensor, cls: torch.Tensor, pos0: torch.Tensor, tiles: int, tokens_per_tile: int) -> None:
+    _chk_bf16(x, cls, pos0)
+    lib = load_library()
+    check(lib.mjv_cls_rows_bf16(x.data_ptr(), _row_stride(x), cls.data_ptr(), pos0.data_ptr(), tiles,
+                                tokens_per_tile, x.shape[1], _stream()), "mjv_cls_rows_bf16")
+
+
+def embed_gather(ids: torch.Tensor, table: torch.Tensor, x: torch.Tensor, skip_id: int) -> None:
+    _chk_bf16(table, x)
+    assert ids.dtype == torch.int32 and ids.is_cuda
+    lib = load_library()
+    check(lib.mjv_embed_gather_bf16(ids.data_ptr(), table.data_ptr(), _row_stride(table), x.data_ptr(),
+                                    _row_stride(x), ids.numel(), x.shape[1], skip_id, table.shape[0], _stream()),
+          "mjv_embed_gather_bf16")
+
+
+def reward_heads(desc: HeadsDesc) -> None:
+    check(load_library().mjv_reward_heads_bf16(C.byref(desc), _stream()), "mjv_reward_heads_bf16")
+
+
+# ------------------------------------------------------------------------------------ profiler access
+def prof_enable(on: bool) -> None:
+    check(load_library().mjv_prof_enable(int(on)), "mjv_prof_enable")
+
+
+def prof_reset() -> None:
+    check(load_library().mjv_prof_reset(), "mjv_prof_reset")
+
+
+def prof_results() -> dict:
+    """{tag: dict(launches, ms, flops, bytes)} after synchronising the recorded events."""
+    lib = load_library()
+    check(lib.mjv_prof_collect(), "mjv_prof_collect")
+    out = {}
+    for i in range(lib.mjv_prof_count()):
+        name, n = C.c_char_p(), C.c_int64()
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        check(lib.mjv_prof_get(i, C.byref(name), C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "mjv_prof_get")
+        out[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+    return out

@@ -1,0 +1,203 @@
+"""Deterministic synthetic weights and inputs (no checkpoints, tokenizer or videos exist offline).
+
+Everything here is a pure function of integer seeds through numpy's counter-based Philox
+generator, so this container (where golden vectors are produced by importing the reference) and
+the GPU box (where the HIP path is checked against them) regenerate bit-identical tensors
+without shipping gigabytes.  Workload layout: SURVEY.md §8(d).
+"""
+from __future__ import annotations
+
+import os
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+# special token ids of the InternVL2 / InternLM2 tokenizer.  92542/92543/525/11353/364 are pinned by
+# scripts/model/moe_reward.py:48; the others are the published ids of the checkpoint's tokenizer.
+IM_END, IM_START = 92542, 92543
+IMG_START_ID, IMG_END_ID, IMG_CONTEXT_ID = 92544, 92545, 92546
+BOS_ID, PAD_ID = 1, 2
+GATING_PATTERN = (92542, 92543, 525, 11353, 364)
+N_TEXT_TOKENS = 138  # non-image tokens of the synthetic prompt (N = 2186 at 8x256 image tokens)
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())]))
+
+
+def _normal(seed: int, name: str, shape, std: float, mean: float = 0.0) -> torch.Tensor:
+    n = int(np.prod(shape))
+    a = _rng(seed, name).standard_normal(n, dtype=np.float32)
+    if std != 1.0:
+        a *= np.float32(std)
+    if mean != 0.0:
+        a += np.float32(mean)
+    return torch.from_numpy(a).reshape(tuple(shape))
+
+
+def state_dict_spec(config) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(key, shape, kind) for every tensor of the reward model's checkpoint (SURVEY.md §8(b) layout)."""
+    v, l = config.vision_config, config.llm_config
+    d, ff, P = v.hidden_size, v.intermediate_size, v.patch_size
+    npos = (v.image_size // P) ** 2 + 1
+    spec: List[Tuple[str, Tuple[int, ...], str]] = []
+    nobj = config.num_objectives
+    spec.append(("reward_transform_matrix", (nobj, nobj), "eye"))
+    p = "model.vision_model.embeddings."
+    spec += [(p + "class_embedding", (1, 1, d), "emb"), (p + "position_embedding", (1, npos, d), "emb"),
+             (p + "patch_embedding.weight", (d, 3, P, P), "w"), (p + "patch_embedding.bias", (d,), "b")]
+    for i in range(v.num_hidden_layers):
+        p = f"model.vision_model.encoder.layers.{i}."
+        spec += [(p + "ls1", (d,), "ls"), (p + "ls2", (d,), "ls"),
+                 (p + "attn.qkv.weight", (3 * d, d), "w")]
+        if v.qkv_bias:
+            spec.append((p + "attn.qkv.bias", (3 * d,), "b"))
+        spec += [(p + "attn.proj.weight", (d, d), "w"), (p + "attn.proj.bias", (d,), "b"),
+                 (p + "mlp.fc1.weight", (ff, d), "w"), (p + "mlp.fc1.bias", (ff,), "b"),
+                 (p + "mlp.fc2.weight", (d, ff), "w"), (p + "mlp.fc2.bias", (d,), "b"),
+                 (p + "norm1.weight", (d,), "g"), (p + "norm1.bias", (d,), "b"),
+                 (p + "norm2.weight", (d,), "g"), (p + "norm2.bias", (d,), "b")]
+    h, lf = l.hidden_size, l.intermediate_size
+    hd = h // l.num_attention_heads
+    qkv_out = (l.num_attention_heads + 2 * l.num_key_value_heads) * hd
+    spec.append(("model.language_model.model.tok_embeddings.weight", (l.vocab_size, h), "w"))
+    for i in range(l.num_hidden_layers):
+        p = f"model.language_model.model.layers.{i}."
+        spec += [(p + "attention.wqkv.weight", (qkv_out, h), "w"), (p + "attention.wo.weight", (h, h), "w"),
+                 (p + "feed_forward.w1.weight", (lf, h), "w"), (p + "feed_forward.w3.weight", (lf, h), "w"),
+                 (p + "feed_forward.w2.weight", (h, lf), "w"),
+                 (p + "attention_norm.weight", (h,), "g"), (p + "ffn_norm.weight", (h,), "g")]
+    spec.append(("model.language_model.model.norm.weight", (h,), "g"))
+    spec.append(("model.language_model.output.weight", (l.vocab_size, h), "lmhead"))
+    c4 = d * int(1 / config.downsample_ratio) ** 2
+    spec += [("model.mlp1.0.weight", (c4,), "g"), ("model.mlp1.0.bias", (c4,), "b"),
+             ("model.mlp1.1.weight", (h, c4), "w"), ("model.mlp1.1.bias", (h,), "b"),
+             ("model.mlp1.3.weight", (h, h), "w"), ("model.mlp1.3.bias", (h,), "b")]
+    spec.append(("regression_layer.weight", (nobj, h), "head"))
+    gh, gn = config.gating_hidden_dim, config.gating_n_hidden
+    for net, nout in (("aspect_gating", config.num_aspects), ("criteria_gating", nobj)):
+        spec.append((f"{net}.logit_scale", (1,), "one"))
+        fin = h
+        for j in range(gn):
+            spec += [(f"{net}.layers.{j}.weight", (gh, fin), "gate"), (f"{net}.layers.{j}.bias", (gh,), "b")]
+            fin = gh
+        spec += [(f"{net}.layers.{gn}.weight", (nout, fin), "gate"), (f"{net}.layers.{gn}.bias", (nout,), "b")]
+    return spec
+
+
+def synth_state_dict(config, seed: int = 0, dtype=torch.bfloat16, head_std: float = 0.05,
+                     gate_std: float = 0.05, lm_head: bool = True) -> Dict[str, torch.Tensor]:
+    """Random-init weights with exact checkpoint keys/shapes.
+
+    Linear/conv/embedding weights N(0, 0.02) (the reference's HF init,
+    modeling_internlm2.py:714-723); biases N(0, 0.02) and norm gains 1+N(0, 0.05) instead of the
+    init's 0/1 so that every bias/gain code path is numerically exercised; reward/gating heads
+    use a larger sigma so scores spread well above bf16 noise (SURVEY.md §7 "hard parts").
+    The LM head is zeros: the reward path never reads it (only ``strict=True`` loading does).
+    """
+    ls0 = float(config.vision_config.initializer_factor)
+
+    def make(item):
+        key, shape, kind = item
+        if kind == "w":
+            t = _normal(seed, key, shape, 0.02)
+        elif kind == "b":
+            t = _normal(seed, key, shape, 0.02)
+        elif kind == "g":
+            t = _normal(seed, key, shape, 0.05, 1.0)
+        elif kind == "ls":
+            t = _normal(seed, key, shape, 0.05 * ls0, ls0)
+        elif kind == "emb":
+            t = _normal(seed, key, shape, 1.0)
+        elif kind == "head":
+            t = _normal(seed, key, shape, head_std)
+        elif kind == "gate":
+            t = _normal(seed, key, shape, gate_std)
+        elif kind == "eye":
+            t = torch.eye(shape[0], dtype=torch.float32)
+        elif kind == "one":
+            t = torch.ones(shape, dtype=torch.float32)
+        elif kind == "lmhead":
+            t = torch.zeros(shape, dtype=dtype)
+        else:
+            raise AssertionError(kind)
+        return key, t.to(dtype)
+
+    items = [it for it in state_dict_spec(config) if lm_head or it[2] != "lmhead"]
+    # every tensor has its own Philox stream, so generation order / threading cannot change values
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+        return dict(pool.map(make, items))
+
+
+def synth_pixel_values(seed: int, video_idx: int, n_tiles: int, image_size: int,
+                       dtype=torch.bfloat16) -> torch.Tensor:
+    """One synthetic video, already in normalised-pixel space: ``[n_tiles, 3, S, S]``.
+
+    Each video gets its own brightness/contrast and a coarse spatial pattern that drifts from
+    frame to frame (so different videos produce visibly different features and score margins are
+    not pure noise), plus unit white noise as in SURVEY.md §8(d).
+    """
+    g = _rng(seed, f"video{video_idx}")
+    S = image_size
+    gain = np.float32(0.5 + 1.5 * g.random())
+    bias = np.float32(g.normal(0.0, 0.7))
+    coarse = g.standard_normal((n_tiles, 3, 8, 8), dtype=np.float32)
+    drift = np.cumsum(coarse, axis=0) / np.sqrt(np.arange(1, n_tiles + 1, dtype=np.float32))[:, None, None, None]
+    rep = -(-S // 8)
+    field = np.repeat(np.repeat(drift, rep, axis=2), rep, axis=3)[:, :, :S, :S]
+    noise = g.standard_normal((n_tiles, 3, S, S), dtype=np.float32)
+    px = gain * (0.8 * field + 0.6 * noise) + bias
+    return torch.from_numpy(np.ascontiguousarray(px)).to(dtype)
+
+
+def synth_input_ids(n_image_tokens: int, caption_seed: int, n_caption: int = 32,
+                    interleave_frames: Optional[int] = None) -> torch.Tensor:
+    """Token ids with the structure of a tokenised MJ-VIDEO prompt: ``[1, n_image_tokens + 138]``.
+
+    ``BOS, <|im_start|> + 61 system ids + <|im_end|>, <|im_start|> user\\n "Frame1: " <img>,
+    <IMG_CONTEXT> * n, </img> \\n, 7 * ("FrameK: <image>\\n" as 4 literal ids), caption ids,
+    <|im_end|><|im_start|>assistant\\n`` - the contiguous image run is the reference's default
+    behaviour.  With ``interleave_frames=F`` the image run is split into F runs,
+    one per "FrameK: <img>...</img>\\n" (what ``num_patches_list=[1]*F`` produces).
+    """
+    fixed = _rng(0, "prompt-fixed")
+    sys_ids = fixed.integers(1000, 60000, size=61).tolist()
+    user_ids = fixed.integers(1000, 60000, size=2).tolist()
+    frame_ids = fixed.integers(1000, 60000, size=(8, 3)).tolist()
+    nl_id = 364
+    cap = _rng(caption_seed, "caption").integers(1000, 60000, size=n_caption).tolist()
+    ids = [BOS_ID, IM_START] + sys_ids + [IM_END, IM_START] + user_ids
+    if interleave_frames:
+        F = interleave_frames
+        assert n_image_tokens % F == 0 and F <= 8
+        per = n_image_tokens // F
+        body: List[int] = []
+        for k in range(F):
+            body += frame_ids[k] + [IMG_START_ID] + [IMG_CONTEXT_ID] * per + [IMG_END_ID, nl_id]
+        # keep the total length identical to the contiguous layout: 7 literal frames <-> 7*(3+1+2-2)
+        filler = 7 * 4 + 3 + 1 + 2 - F * 6
+        ids += body + (fixed.integers(1000, 60000, size=max(filler, 0)).tolist())
+    else:
+        ids += frame_ids[0] + [IMG_START_ID] + [IMG_CONTEXT_ID] * n_image_tokens + [IMG_END_ID, nl_id]
+        for k in range(1, 8):
+            ids += frame_ids[k] + [nl_id]
+    ids += cap + list(GATING_PATTERN)
+    t = torch.tensor(ids, dtype=torch.long).unsqueeze(0)
+    if not interleave_frames:
+        assert t.shape[1] == n_image_tokens + N_TEXT_TOKENS, t.shape
+    return t
+
+
+def pad_batch(ids_list: List[torch.Tensor], pad_id: int = PAD_ID, length: Optional[int] = None):
+    """Right-pad ``[1, N_i]`` id rows to ``[B, N]`` as the reference collator does (dataset.py:445-469)."""
+    n = max(int(t.shape[-1]) for t in ids_list) if length is None else length
+    ids = torch.full((len(ids_list), n), pad_id, dtype=torch.long)
+    mask = torch.zeros((len(ids_list), n), dtype=torch.long)
+    for i, t in enumerate(ids_list):
+        k = int(t.shape[-1])
+        ids[i, :k] = t.reshape(-1)
+        mask[i, :k] = 1
+    return ids, mask

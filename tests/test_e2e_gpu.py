@@ -1,0 +1,196 @@
+"""End-to-end parity on the MI355X: the HIP forward against (a) golden vectors produced by the reference
+itself (tests/golden/*.npz, see make_golden.py) and (b) the oracle run on the same seeded inputs.
+
+Tolerance (stated, bf16): the reference's own bf16 run deviates from its fp32 run by a measurable noise
+floor (stored next to every golden vector as fp32/*).  The HIP path has the same rounding points but a
+different fp32 accumulation order, i.e. it is another sample of that same noise.  Every output field must
+therefore satisfy   |hip - ref_bf16| <= TOL_FACTOR * noise_floor(field) + ATOL_FLOOR   where noise_floor is
+max|ref_bf16 - ref_fp32| over the fixture set of that configuration.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import FIELDS, build_hip_model, case_inputs, load_golden, make_cfg
+
+pytestmark = pytest.mark.gpu
+TOL_FACTOR = 2.0
+ATOL_FLOOR = 2e-3
+
+
+def noise_floor(npz, prefixes, field):
+    return max(float(np.abs(npz[f"{p}/{field}"] - npz[f"{p}/fp32/{field}"]).max()) for p in prefixes
+               if f"{p}/fp32/{field}" in npz.files)
+
+
+def rel_l2(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def test_tiny_cases_against_golden(cuda):
+    from mj_video_amd import synth
+    npz, meta = load_golden("tiny")
+    names = [c["name"] for c in meta["cases"]]
+    report = []
+    for case in meta["cases"]:
+        name = case["name"]
+        cfg = make_cfg("tiny", case["image_size"], case["vit_image_size"])
+        sd = synth.synth_state_dict(cfg, seed=case["weight_seed"], dtype=torch.float32)
+        model = build_hip_model(cfg, sd, cuda)
+        px, ids, mask, _ = case_inputs(cfg, case["videos"], case["pixel_seed"], case["image_size"])
+        model.debug_probes = {}
+        out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+        torch.cuda.synchronize()
+        # layer-by-layer first: localises a broken kernel instead of a vague score mismatch
+        for key, t in model.debug_probes.items():
+            ref = npz[f"{name}/probe/{key}"]
+            got = t.float().cpu().numpy()
+            if key.startswith("llm_"):
+                # golden is right-padded [B, N, C]; ours is packed
+                lens = [int(m.sum()) for m in mask]
+                ref = np.concatenate([ref[b, :lens[b]] for b in range(len(lens))], axis=0)
+            assert got.shape == ref.shape, (name, key, got.shape, ref.shape)
+            err = rel_l2(got, ref)
+            assert np.isfinite(got).all(), (name, key)
+            assert err < 0.03, f"{name}:{key} relative L2 error {err:.4f}"
+            report.append((name, key, err))
+        for f in FIELDS:
+            got = getattr(out, f).float().cpu().numpy()
+            ref = npz[f"{name}/{f}"]
+            assert got.shape == ref.shape, (name, f, got.shape, ref.shape)
+            if f in ("hidden_state", "prompt_embedding"):
+                assert rel_l2(got, ref) < 0.03, (name, f, rel_l2(got, ref))
+                continue
+            tol = TOL_FACTOR * noise_floor(npz, names, f) + ATOL_FLOOR
+            d = float(np.abs(got - ref).max())
+            assert d <= tol, f"{name}:{f} max|d|={d:.4e} > tol {tol:.4e}"
+        assert out.score.dtype == torch.float32 and out.aspect_scores.dtype == torch.float32
+        assert out.rewards.dtype == torch.bfloat16
+    worst = sorted(report, key=lambda r: -r[2])[:5]
+    print("worst probe errors:", worst)
+
+
+def _full_case(cuda, tag, image_size):
+    from mj_video_amd import synth
+    npz, meta = load_golden(tag)
+    cfg = make_cfg("2b", image_size)
+    sd = synth.synth_state_dict(cfg, seed=meta["weight_seed"], lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
+        cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)  # loaded (strict) but never read
+    model = build_hip_model(cfg, sd, cuda)
+    with_fp32 = [f"v{v['video_idx']}" for v in meta["videos"] if f"v{v['video_idx']}/fp32/score" in npz.files]
+    # batch all videos of the fixture in ONE forward (the reference ran them one by one: packing must not matter)
+    px, ids, mask, _ = case_inputs(cfg, meta["videos"], meta["pixel_seed"], image_size)
+    model.debug_probes = {}
+    out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+    torch.cuda.synchronize()
+    probes = model.debug_probes
+    tiles = meta["videos"][0]["n_tiles"]
+    for i, v in enumerate(meta["videos"]):
+        p = f"v{v['video_idx']}"
+        if f"{p}/probe/vit_embed_head" in npz.files:
+            sl = slice(i * tiles, (i + 1) * tiles)
+            for key, src in (("vit_embed_head", "vit_embed"), ("vit_layer0_head", "vit_layer0"), ("vit_embeds_head", "vit_embeds")):
+                got = probes[src][sl, :4, :16].float().cpu().numpy()
+                assert rel_l2(got, npz[f"{p}/probe/{key}"]) < 0.03, (tag, p, key, rel_l2(got, npz[f"{p}/probe/{key}"]))
+        for f in FIELDS:
+            got = getattr(out, f)[i].float().cpu().numpy()
+            ref = npz[f"{p}/{f}"][0]
+            if f in ("hidden_state", "prompt_embedding"):
+                assert rel_l2(got, ref) < 0.03, (tag, p, f, rel_l2(got, ref))
+                continue
+            tol = TOL_FACTOR * noise_floor(npz, with_fp32, f) + ATOL_FLOOR
+            d = float(np.abs(got - ref).max())
+            print(f"{tag} {p} {f}: max|d|={d:.3e} tol={tol:.3e}")
+            assert d <= tol, f"{tag}:{p}:{f} max|d|={d:.4e} > tol {tol:.4e}"
+    return model, cfg
+
+
+def test_full_c1_against_golden(cuda):
+    """MJ-VIDEO-2B dims, 8 frames @224 (BASELINE.json configs[0] shape), 4 videos batched"""
+    _full_case(cuda, "full_c1", 224)
+
+
+def test_full_c2_against_golden(cuda):
+    """MJ-VIDEO-2B dims, 8 frames @448, N = 2186 (BASELINE.json configs[1] shape), 2 videos batched"""
+    _full_case(cuda, "full_c2", 448)
+
+
+def test_rank_agreement_c1(cuda):
+    """Fixed synthetic set of pairs scored by the reference (rankset_c1): pairwise preference, good/bad flag and
+    Spearman rho of the HIP scores vs the reference's, all >= 0.999 on pairs whose margin exceeds the noise floor."""
+    from mj_video_amd import synth
+    from mj_video_amd.chat_input import num_image_tokens_per_tile
+    try:
+        npz, meta = load_golden("rankset_c1")
+    except FileNotFoundError:
+        pytest.skip("rankset_c1 fixture not generated")
+    ref = npz["ref_bf16"]
+    ref32 = npz["ref_fp32"]
+    P = min(ref.shape[0], 256)
+    cfg = make_cfg("2b", meta["image_size"])
+    sd = synth.synth_state_dict(cfg, seed=meta["weight_seed"], lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
+        cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
+    model = build_hip_model(cfg, sd, cuda)
+    nt = meta["n_tiles"]
+    got = np.zeros((P, 2, 34), dtype=np.float32)
+    PB = 8  # pairs per forward
+    for p0 in range(0, P, PB):
+        px, ids = [], []
+        for p in range(p0, min(P, p0 + PB)):
+            row = synth.synth_input_ids(num_image_tokens_per_tile(cfg) * nt, caption_seed=meta["caption_seed_base"] + p)
+            for j in range(2):
+                px.append(synth.synth_pixel_values(meta["pixel_seed"], 2 * p + j, nt, meta["image_size"]))
+                ids.append(row)
+        ids_b, mask = synth.pad_batch(ids)
+        model.forward(torch.cat(px).to(cuda), ids_b.to(cuda), mask.to(cuda))
+        got[p0:p0 + len(px) // 2] = model.last_packed34.float().cpu().numpy().reshape(-1, 2, 34)
+    ref = ref[:P]
+    have32 = ~np.isnan(ref32[:P, 0, 0])
+    noise = float(np.abs(ref[have32][..., 0] - ref32[:P][have32][..., 0]).max())
+    d = np.abs(got[..., 0] - ref[..., 0])
+    print(f"pairs={P} score noise floor (ref bf16 vs fp32)={noise:.3e}  max|hip-ref|={d.max():.3e} mean={d.mean():.3e}")
+    margin = np.abs(ref[:, 0, 0] - ref[:, 1, 0])
+    decisive = margin > 4 * noise
+    agree = np.sign(got[:, 0, 0] - got[:, 1, 0]) == np.sign(ref[:, 0, 0] - ref[:, 1, 0])
+    print(f"decisive pairs {int(decisive.sum())}/{P}; agreement all={agree.mean():.4f} decisive={agree[decisive].mean():.4f}; "
+          f"min decisive margin/noise={margin[decisive].min() / noise:.1f}")
+    assert decisive.sum() >= 0.8 * P, "synthetic set has too many near-ties to be meaningful"
+    assert agree[decisive].mean() >= 0.999
+    from scipy.stats import spearmanr
+    rho = spearmanr(got[..., 0].ravel(), ref[..., 0].ravel()).correlation
+    print(f"spearman rho={rho:.6f}")
+    assert rho >= 0.999
+    good = (got[..., 0] > 0) == (ref[..., 0] > 0)
+    far = np.abs(ref[..., 0]) > 4 * noise
+    assert good[far].mean() >= 0.999
+    assert d.max() <= TOL_FACTOR * noise + ATOL_FLOOR
+
+
+def test_error_behaviour(cuda):
+    """the reference's ValueErrors (moe_reward.py:57,218-219) and the build's loud failures"""
+    from mj_video_amd import synth
+    cfg = make_cfg("tiny", 56)
+    sd = synth.synth_state_dict(cfg, seed=3, dtype=torch.float32)
+    model = build_hip_model(cfg, sd, cuda)
+    px = synth.synth_pixel_values(1, 0, 2, 56).to(cuda)
+    ids = synth.synth_input_ids(8, 1)
+    bad = ids.clone()
+    bad[0, -1] = 5  # break the gating pattern
+    with pytest.raises(ValueError, match="Token pattern not found"):
+        model.forward(px, bad.to(cuda), torch.ones_like(bad).to(cuda))
+    model.config.pad_token_id = None
+    with pytest.raises(ValueError, match="Cannot handle batch sizes > 1"):
+        model.forward(torch.cat([px, px]), torch.cat([ids, ids]).to(cuda), None)
+    model.config.pad_token_id = synth.PAD_ID
+    with pytest.raises(ValueError, match="IMG_CONTEXT"):
+        model.forward(px[:1], ids.to(cuda), None)
+    with pytest.raises(TypeError):
+        model.forward(px.float(), ids.to(cuda), None)
+    # attention_mask=None and pad_token_id=None with batch 1 both work and agree
+    a = model.forward(px, ids.to(cuda), None).score.item()
+    model.config.pad_token_id = None
+    b = model.forward(px, ids.to(cuda), torch.ones_like(ids).to(cuda)).score.item()
+    assert a == b

@@ -1,0 +1,289 @@
+"""Per-kernel parity on the MI355X: every C-ABI op against a plain PyTorch fp32 reference of the same op
+with the reference's bf16 rounding points.  Tolerances are stated per test: bf16 has 8 significant bits,
+so one unit in the last place is 2^-8 relative; fp32 accumulation ORDER differs between an MFMA tile
+loop and a CPU GEMM, which can flip the final rounding by 1 ulp (2 ulps after a second rounding point).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import bf16_ulps
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(*shape, std=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(BF)
+
+
+def assert_close_bf16(out, ref, max_ulps, frac_exact=0.0, atol=0.0, what=""):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    ulps = bf16_ulps(out, ref)
+    ok = (ulps <= max_ulps) | ((out - ref).abs() <= atol)
+    assert ok.all(), (f"{what}: {int((~ok).sum())} of {ok.numel()} elements off by more than {max_ulps} bf16 ulps "
+                      f"(max {int(ulps.max())}, max abs err {(out - ref).abs().max().item():.3e})")
+    if frac_exact:
+        fe = (ulps == 0).float().mean().item()
+        assert fe >= frac_exact, f"{what}: only {fe:.4f} of elements bit-identical (< {frac_exact})"
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 128), (1, 256, 256), (1025, 3072, 1024), (77, 8, 64)])
+def test_gemm_bias(cuda, M, N, K):
+    from mj_video_amd import ops
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, std=0.05, seed=2), rnd(N, std=0.1, seed=3)
+    out = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(a.to(cuda), w.to(cuda), out, ops.EPI_BIAS, bias=b.to(cuda))
+    ref = (a.float() @ w.float().t() + b.float()).to(BF)
+    # one rounding point, accumulation order differs: <= 1 ulp, and the vast majority bit-identical
+    assert_close_bf16(out, ref, 1, frac_exact=0.98, atol=1e-6, what="gemm_bias")
+    out2 = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(a.to(cuda), w.to(cuda), out2, ops.EPI_BIAS)
+    assert_close_bf16(out2, (a.float() @ w.float().t()).to(BF), 1, frac_exact=0.98, atol=1e-6, what="gemm_nobias")
+
+
+def test_gemm_exact_integers(cuda):
+    """small-integer operands: every product and partial sum is exact in fp32, so the result must be bit-exact
+    (catches any fragment-layout / swizzle / transposition mistake; asymmetric A and W)"""
+    from mj_video_amd import ops
+    M, N, K = 200, 136, 192
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-4, 5, (M, K), generator=g).float().to(BF)
+    w = torch.randint(-3, 4, (N, K), generator=g).float().to(BF)
+    out = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(a.to(cuda), w.to(cuda), out, ops.EPI_BIAS)
+    ref = (a.float() @ w.float().t()).to(BF)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm_gelu_relu(cuda):
+    from mj_video_amd import ops
+    M, N, K = 257, 512, 128
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, std=0.1, seed=2), rnd(N, std=0.1, seed=3)
+    lin = (a.float() @ w.float().t() + b.float()).to(BF)
+    out = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(a.to(cuda), w.to(cuda), out, ops.EPI_BIAS_GELU, bias=b.to(cuda))
+    # two rounding points (Linear, GELU): a 1-ulp flip of the first can move the second by up to 2 ulps
+    assert_close_bf16(out, F.gelu(lin.float()).to(BF), 2, frac_exact=0.97, atol=2e-3, what="gemm_gelu")
+    ops.gemm(a.to(cuda), w.to(cuda), out, ops.EPI_BIAS_RELU, bias=b.to(cuda))
+    assert_close_bf16(out, F.relu(lin), 1, frac_exact=0.98, atol=1e-6, what="gemm_relu")
+
+
+def test_gemm_scale_res_and_rowmaps(cuda):
+    from mj_video_amd import ops
+    M, N, K = 320, 256, 128
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, std=0.1, seed=2), rnd(N, std=0.1, seed=3)
+    ls, res = rnd(N, std=0.5, seed=4), rnd(M, N, seed=5)
+    lin = (a.float() @ w.float().t() + b.float()).to(BF)
+    ref = (res.float() + (lin.float() * ls.float()).to(BF).float()).to(BF)
+    x = res.clone().to(cuda)
+    ops.gemm(a.to(cuda), w.to(cuda), x, ops.EPI_SCALE_RES, bias=b.to(cuda), scale=ls.to(cuda), res=x)  # in place
+    assert_close_bf16(x, ref, 2, frac_exact=0.97, atol=4e-3, what="gemm_scale_res")
+    # residual only (LLM wo / w2)
+    x = res.clone().to(cuda)
+    ops.gemm(a.to(cuda), w.to(cuda), x, ops.EPI_SCALE_RES, res=x)
+    ref2 = (res.float() + (a.float() @ w.float().t()).to(BF).float()).to(BF)
+    assert_close_bf16(x, ref2, 2, frac_exact=0.97, atol=4e-3, what="gemm_res")
+    # patch-embed style: residual row = 1 + m % 64 of a table, output skips one CLS slot per group of 64
+    table = rnd(65, N, seed=6)
+    out = torch.zeros(M + M // 64, N, dtype=BF, device=cuda)
+    ops.gemm(a.to(cuda), w.to(cuda), out, ops.EPI_SCALE_RES, bias=b.to(cuda), res=table.to(cuda), res_mod=64, res_off=1,
+             out_group=64, out_pad=1)
+    ref3 = (lin.float() + table[1:].repeat(M // 64, 1).float()).to(BF).view(M // 64, 64, N)
+    got = out.cpu().view(M // 64, 65, N)
+    assert_close_bf16(got[:, 1:], ref3, 2, frac_exact=0.97, atol=4e-3, what="gemm_patch")
+    assert (got[:, 0] == 0).all()
+    # explicit output rows (splice)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(7)).to(torch.int32)
+    out = torch.zeros(M, N, dtype=BF, device=cuda)
+    ops.gemm(a.to(cuda), w.to(cuda), out, ops.EPI_BIAS, bias=b.to(cuda), out_rows=perm.to(cuda))
+    assert_close_bf16(out.cpu()[perm.long()], lin, 1, frac_exact=0.98, atol=1e-6, what="gemm_out_rows")
+
+
+def test_gemm_silu_mul(cuda):
+    from mj_video_amd import ops
+    M, FF, K = 130, 256, 128
+    a, w1, w3 = rnd(M, K, seed=1), rnd(FF, K, std=0.1, seed=2), rnd(FF, K, std=0.1, seed=3)
+    w13 = torch.stack([w1.view(FF // 16, 16, K), w3.view(FF // 16, 16, K)], dim=1).reshape(2 * FF, K).contiguous()
+    out = torch.empty(M, FF, dtype=BF, device=cuda)
+    ops.gemm(a.to(cuda), w13.to(cuda), out, ops.EPI_SILU_MUL)
+    g = (a.float() @ w1.float().t()).to(BF)
+    u = (a.float() @ w3.float().t()).to(BF)
+    ref = F.silu(g) * u  # bf16 ops, as modeling_internlm2.py:262
+    assert_close_bf16(out, ref, 3, frac_exact=0.95, atol=2e-3, what="gemm_silu_mul")
+
+
+# ---------------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("rows,dim", [(5, 128), (1025, 1024), (300, 4096)])
+def test_layernorm(cuda, rows, dim):
+    from mj_video_amd import ops
+    x, g, b = rnd(rows, dim, seed=1), (1 + 0.1 * torch.randn(dim)).to(BF), (0.1 * torch.randn(dim)).to(BF)
+    out = torch.empty(rows, dim, dtype=BF, device=cuda)
+    ops.layernorm(x.to(cuda), g.to(cuda), b.to(cuda), out, 1e-6)
+    ref = F.layer_norm(x.float(), (dim,), g.float(), b.float(), 1e-6).to(BF)
+    assert_close_bf16(out, ref, 1, frac_exact=0.98, atol=1e-6, what="layernorm")
+
+
+def test_layernorm_pixel_shuffle(cuda):
+    from mj_video_amd import ops
+    tiles, G, d = 3, 8, 128
+    x = rnd(tiles * (G * G + 1), d, seed=1)
+    g, b = (1 + 0.1 * torch.randn(4 * d)).to(BF), (0.1 * torch.randn(4 * d)).to(BF)
+    out = torch.empty(tiles * (G // 2) ** 2, 4 * d, dtype=BF, device=cuda)
+    ops.layernorm(x.to(cuda), g.to(cuda), b.to(cuda), out, 1e-5, gather_grid=G)
+    # independent restatement of modeling_internvl_chat.py:228-242,255-260 with tensor ops
+    v = x.view(tiles, G * G + 1, d)[:, 1:, :].reshape(tiles, G, G, d)
+    n, w_, h_, c = v.shape
+    v = v.view(n, w_, h_ // 2, c * 2).permute(0, 2, 1, 3).contiguous()
+    v = v.view(n, h_ // 2, w_ // 2, c * 4).permute(0, 2, 1, 3).contiguous().view(n, -1, 4 * d)
+    ref = F.layer_norm(v.float(), (4 * d,), g.float(), b.float(), 1e-5).to(BF).view(-1, 4 * d)
+    assert_close_bf16(out, ref, 1, frac_exact=0.98, atol=1e-6, what="layernorm_pixshuf")
+
+
+def test_rmsnorm_and_gather(cuda):
+    from mj_video_amd import ops
+    rows, dim = 333, 2048
+    x, w = rnd(rows, dim, seed=1), (1 + 0.1 * torch.randn(dim)).to(BF)
+
+    def ref_fn(t):
+        h = t.float()
+        h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-5)
+        return w * h.to(BF)
+
+    out = torch.empty(rows, dim, dtype=BF, device=cuda)
+    ops.rmsnorm(x.to(cuda), w.to(cuda), out, 1e-5)
+    assert_close_bf16(out, ref_fn(x), 1, frac_exact=0.98, atol=1e-6, what="rmsnorm")
+    idx = torch.tensor([5, 0, 332, 17], dtype=torch.int32)
+    out = torch.empty(4, dim, dtype=BF, device=cuda)
+    ops.rmsnorm(x.to(cuda), w.to(cuda), out, 1e-5, row_index=idx.to(cuda))
+    assert_close_bf16(out, ref_fn(x[idx.long()]), 1, frac_exact=0.98, atol=1e-6, what="rmsnorm_gather")
+
+
+def test_rope_split(cuda):
+    from mj_video_amd import ops
+    rows, KV, G, D = 70, 2, 2, 128
+    qkv = rnd(rows, KV * (G + 2) * D, seed=1)
+    pos = torch.arange(rows, dtype=torch.int32) % 50
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.einsum("i,j->ij", torch.arange(64).float(), inv)
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos().to(BF), emb.sin().to(BF)
+    q = torch.empty(rows, KV * G * D, dtype=BF, device=cuda)
+    k = torch.empty(rows, KV * D, dtype=BF, device=cuda)
+    ops.rope_split(qkv.to(cuda), q, k, cos.to(cuda), sin.to(cuda), pos.to(cuda), KV, G)
+    t = qkv.view(rows, KV, G + 2, D)
+
+    def rot(x):
+        return torch.cat((-x[..., D // 2:], x[..., :D // 2]), -1)
+
+    c, s = cos[pos.long()][:, None, None, :], sin[pos.long()][:, None, None, :]
+    qr = (t[:, :, :G] * c) + (rot(t[:, :, :G]) * s)          # bf16 ops: modeling_internlm2.py:240-247
+    kr = (t[:, :, G:G + 1] * c) + (rot(t[:, :, G:G + 1]) * s)
+    assert torch.equal(q.cpu(), qr.reshape(rows, -1))           # elementwise bf16 arithmetic: bit-exact
+    assert torch.equal(k.cpu(), kr.reshape(rows, -1))
+
+
+def test_patchify_cls_embed(cuda):
+    from mj_video_amd import ops
+    tiles, S, P = 2, 56, 14
+    px = rnd(tiles, 3, S, S, seed=1)
+    kp = 640
+    out = torch.empty(tiles * 16, kp, dtype=BF, device=cuda)
+    ops.patchify(px.to(cuda), out, P)
+    ref = F.unfold(px.float(), kernel_size=P, stride=P).transpose(1, 2).reshape(tiles * 16, 3 * P * P).to(BF)
+    assert torch.equal(out.cpu()[:, :588], ref)
+    assert (out.cpu()[:, 588:] == 0).all()
+    x = torch.zeros(tiles * 17, 128, dtype=BF, device=cuda)
+    cls, p0 = rnd(128, seed=2), rnd(128, seed=3)
+    ops.cls_rows(x, cls.to(cuda), p0.to(cuda), tiles, 17)
+    assert torch.equal(x.cpu()[0], cls + p0) and torch.equal(x.cpu()[17], cls + p0) and (x.cpu()[1:17] == 0).all()
+    table = rnd(1000, 256, seed=4)
+    ids = torch.tensor([3, 999, 7, 7, 0, 500], dtype=torch.int32)
+    xo = torch.zeros(6, 256, dtype=BF, device=cuda)
+    ops.embed_gather(ids.to(cuda), table.to(cuda), xo, 7)
+    exp = table[ids.long()].clone()
+    exp[2:4] = 0
+    assert torch.equal(xo.cpu(), exp)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_reference(q, k, v, lens, H, G, D, causal, scale, mode):
+    """fp32 reference with the reference's score rounding; q [N, H*D], k/v [N, (H/G)*D] packed."""
+    out = torch.zeros(q.shape[0], H * D)
+    s0 = 0
+    for L in lens:
+        for h in range(H):
+            qh = q[s0:s0 + L, h * D:(h + 1) * D].float()
+            kh = k[s0:s0 + L, (h // G) * D:(h // G + 1) * D].float()
+            vh = v[s0:s0 + L, (h // G) * D:(h // G + 1) * D].float()
+            sc = qh @ kh.t()
+            sc = (sc.to(BF).float() * scale).to(BF).float() if mode else (sc * scale).to(BF).float()
+            if causal:
+                sc = sc.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
+            p = torch.softmax(sc, -1).to(BF).float()
+            out[s0:s0 + L, h * D:(h + 1) * D] = p @ vh
+        s0 += L
+    return out.to(BF)
+
+
+@pytest.mark.parametrize("D,H,G,causal,lens", [
+    (64, 2, 1, False, [17, 17, 17]),
+    (64, 16, 1, False, [1025, 1025]),
+    (64, 2, 1, False, [257, 64, 129]),
+    (128, 2, 2, True, [150]),
+    (128, 4, 2, True, [650, 131, 64, 1]),
+    (128, 16, 2, True, [2186]),
+])
+def test_attention(cuda, D, H, G, causal, lens):
+    from mj_video_amd import ops
+    N = sum(lens)
+    KVH = H // G
+    q, k, v = rnd(N, H * D, seed=1), rnd(N, KVH * D, seed=2), rnd(N, KVH * D, seed=3)
+    scale = D ** -0.5
+    mode = 1 if causal else 0
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    out = torch.empty(N, H * D, dtype=BF, device=cuda)
+    ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), out, cu.to(cuda), max(lens), H, G, D, causal, scale, mode)
+    ref = attn_reference(q, k, v, lens, H, G, D, causal, scale, mode)
+    # P is rounded to bf16 before (ours) vs after (reference) normalisation: independent 2^-9 relative errors
+    # on each of the L terms -> error of the output ~ 2^-9 * |v| / sqrt(effective keys); 2 ulps + small atol
+    err = (out.float().cpu() - ref.float()).abs()
+    assert torch.isfinite(out.float()).all()
+    assert err.max().item() < 0.03, f"max abs err {err.max().item()}"
+    assert_close_bf16(out, ref, 2, atol=0.02, what="attention")
+    assert (bf16_ulps(out.float().cpu(), ref.float()) <= 1).float().mean() > 0.9
+
+
+def test_attention_exact_selection(cuda):
+    """one-hot softmax (a huge score on one key): output must equal that key's V row bit for bit; checks the
+    key<->value pairing of the transposed LDS reads and the causal/ragged masks"""
+    from mj_video_amd import ops
+    D, H, L = 128, 2, 200
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(L, D, generator=g).to(BF)
+    target = torch.randint(0, L, (L,), generator=g)
+    target = torch.minimum(target, torch.arange(L))          # causal: only keys <= query
+    # key i = e_(i mod 64) + e_(64 + i div 64): unique per key, so q = 2048 * key_target scores 4096 on the
+    # target, <= 2048 on every other key -> softmax is one-hot after the 1/sqrt(D) scaling
+    kk = torch.zeros(L, D)
+    for i in range(L):
+        kk[i, i % 64] = 1.0
+        kk[i, 64 + i // 64] = 1.0
+    qq = torch.zeros(L, D)
+    for i in range(L):
+        t = int(target[i])
+        qq[i, t % 64] = 2048.0
+        qq[i, 64 + t // 64] = 2048.0
+    q = qq.to(BF).repeat(1, H)
+    k = kk.to(BF)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    out = torch.empty(L, H * D, dtype=BF, device=cuda)
+    ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), out, cu.to(cuda), L, H, H, D, True, 1.0 / math.sqrt(D), 1)
+    exp = v[target]
+    assert torch.equal(out.cpu()[:, :D], exp) and torch.equal(out.cpu()[:, D:], exp)

@@ -1,0 +1,57 @@
+"""Shared helpers for the parity tests (test infrastructure only)."""
+import copy
+import json
+import os
+
+import numpy as np
+import torch
+
+import mj_video_amd  # noqa: F401
+from mj_video_amd import configuration as C, synth
+from mj_video_amd.chat_input import num_image_tokens_per_tile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+FIELDS = ("rewards", "hidden_state", "prompt_embedding", "criteria_gating_output", "aspect_gating_output",
+          "aspect_weights", "score", "weighted_scores", "aspect_scores")
+
+
+def make_cfg(kind, image_size, vit_image_size=None):
+    cd = C.tiny_config_dict(image_size) if kind == "tiny" else C.mjvideo_2b_config_dict(image_size)
+    if vit_image_size is not None:
+        cd["vision_config"]["image_size"] = vit_image_size
+    return C.InternVLChatRewardModelingConfig(**copy.deepcopy(cd), **C.mjvideo_head_kwargs())
+
+
+def load_golden(tag):
+    return np.load(os.path.join(GOLDEN, f"{tag}.npz")), json.load(open(os.path.join(GOLDEN, f"{tag}.json")))
+
+
+def case_inputs(cfg, case_videos, pixel_seed, image_size):
+    px, ids = [], []
+    for v in case_videos:
+        px.append(synth.synth_pixel_values(pixel_seed, v["video_idx"], v["n_tiles"], image_size))
+        ids.append(synth.synth_input_ids(num_image_tokens_per_tile(cfg) * v["n_tiles"], v["caption_seed"],
+                                         interleave_frames=v.get("interleave")))
+    ids_b, mask = synth.pad_batch(ids)
+    return torch.cat(px), ids_b, mask, ids
+
+
+def build_hip_model(cfg, sd, device):
+    from mj_video_amd.modeling import InternVLChatRewardModeling
+    model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16)
+    model.load_state_dict(sd, strict=True)
+    model.config.pad_token_id = synth.PAD_ID
+    model = model.to(torch.bfloat16).to(device)
+    model.model.img_context_token_id = synth.IMG_CONTEXT_ID
+    model.eval()
+    return model
+
+
+def bf16_ulps(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """distance in bf16 units-in-the-last-place between two bf16-representable float tensors"""
+    ai = a.to(torch.bfloat16).view(torch.int16).to(torch.int32)
+    bi = b.to(torch.bfloat16).view(torch.int16).to(torch.int32)
+    ai = torch.where(ai < 0, -(ai & 0x7fff), ai)
+    bi = torch.where(bi < 0, -(bi & 0x7fff), bi)
+    return (ai - bi).abs()
