@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: video-pairs scored/sec, MJ-VIDEO-2B, 8 frames @448^2 (max_num=1), bf16.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the reward-scoring hot path over one batch of synthetic pairs per GPU
+(BASELINE.json configs[1]: 4 pairs = 8 videos x 8 tiles, N = 2186 tokens per video), inputs already
+resident in HBM, random-init weights of the exact MJ-VIDEO-2B architecture.  Pairs are sharded
+data-parallel (weak scaling: every rank scores its own 4 pairs per step); the only collective is one
+RCCL all-gather of the [pairs, 2, 34] fp32 score block per step.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  "roofline":     dominant kernel's algorithmic TFLOP/s (HIP events on the launch stream, recorded inside the
+                  timed region by the library's opt-in profiler) against the 2.5 PFLOP/s dense bf16 MFMA peak,
+  "cpu_baseline": the oracle (CPU restatement of the reference forward, bf16, LM head included as the
+                  reference executes it) timed on this host on ONE video of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import mj_video_amd  # noqa: E402,F401
+from mj_video_amd import configuration as C, ops, synth  # noqa: E402
+from mj_video_amd.chat_input import num_image_tokens_per_tile  # noqa: E402
+from mj_video_amd.modeling import InternVLChatRewardModeling  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
+ALGO_TFLOP_PER_PAIR = 25.8       # 12.9 TFLOP per video at C2 (causal-halved, LM head skipped)
+
+
+def random_init_on_device(model, config, device, seed):
+    """Random-init weights of the architecture, generated directly in HBM (same distributions as synth)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ls0 = float(config.vision_config.initializer_factor)
+    params = dict(model.named_parameters())
+    for key, shape, kind in synth.state_dict_spec(config):
+        p = params[key]
+        assert tuple(p.shape) == tuple(shape), key
+        if kind in ("w", "b"):
+            p.normal_(0.0, 0.02, generator=g)
+        elif kind == "g":
+            p.normal_(1.0, 0.05, generator=g)
+        elif kind == "ls":
+            p.normal_(ls0, 0.05 * ls0, generator=g)
+        elif kind == "emb":
+            p.normal_(0.0, 1.0, generator=g)
+        elif kind in ("head", "gate"):
+            p.normal_(0.0, 0.05, generator=g)
+        elif kind == "eye":
+            p.copy_(torch.eye(shape[0], device=device))
+        elif kind == "one":
+            p.fill_(1.0)
+        elif kind == "lmhead":
+            p.zero_()
+
+
+def cpu_baseline(config, image_size, n_tiles, threads):
+    """Oracle forward of one video of the workload on the host CPU (checker code, timed only as a baseline)."""
+    from oracle import ref_cpu
+    torch.set_num_threads(threads)
+    sd = synth.synth_state_dict(config, seed=0)
+    px = synth.synth_pixel_values(300, 0, n_tiles, image_size)
+    ids = synth.synth_input_ids(num_image_tokens_per_tile(config) * n_tiles, 0)
+    t0 = time.time()
+    ref_cpu.reward_forward(sd, config, px, ids, torch.ones_like(ids), synth.IMG_CONTEXT_ID, synth.PAD_ID, lm_head=True)
+    dt = time.time() - t0
+    return 0.5 / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=4, help="pairs per GPU per step (BASELINE.json configs[1]: 4)")
+    ap.add_argument("--image-size", type=int, default=448)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs: the scoring path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    S, F = args.image_size, args.frames
+    cfg = C.InternVLChatRewardModelingConfig(**C.mjvideo_2b_config_dict(S), **C.mjvideo_head_kwargs())
+    model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16, device=dev)
+    random_init_on_device(model, cfg, dev, seed=1234)
+    model.config.pad_token_id = synth.PAD_ID
+    model.model.img_context_token_id = synth.IMG_CONTEXT_ID
+    model.eval()
+
+    n_videos = 2 * args.pairs
+    per_tile = num_image_tokens_per_tile(cfg)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    px = torch.randn(n_videos * F, 3, S, S, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    ids_list = []
+    for p in range(args.pairs):
+        row = synth.synth_input_ids(per_tile * F, caption_seed=rank * 1000 + p)
+        ids_list += [row, row]  # both videos of a pair share the caption
+    ids, mask = synth.pad_batch(ids_list)
+    ids, mask = ids.to(dev), mask.to(dev)
+    seq_len = int(ids.shape[1])
+    gathered = torch.empty(world * n_videos, 34, dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        model.forward(px, ids, mask)
+        block = model.last_packed34
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, block)
+            return gathered
+        return block
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof = not args.no_prof
+    if prof:
+        ops.prof_reset()
+        ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if prof:
+        ops.prof_enable(False)
+    if not torch.isfinite(out).all():
+        raise SystemExit("non-finite scores")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_pairs = args.pairs * world * args.steps
+        value = total_pairs / elapsed
+        line = {
+            "metric": "video-pairs scored/sec, MJ-VIDEO-2B 8-frame bf16",
+            "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"MJ-VIDEO-2B, batch={args.pairs} pairs per GPU, {F} frames @{S}^2 max_num=1, "
+                                   f"N={seq_len} tokens/video, random-init weights, inputs resident in HBM",
+                       "pairs_per_gpu_per_step": args.pairs, "global_pairs_per_step": args.pairs * world,
+                       "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
+            "frac_of_mfma_roofline": round(value * ALGO_TFLOP_PER_PAIR / (MFMA_BF16_PEAK_TFLOPS * world), 4)
+            if (S, F) == (448, 8) else None,
+        }
+        if prof:
+            res = ops.prof_results()
+            tot = sum(r["ms"] for r in res.values())
+            dom = max(res.items(), key=lambda kv: kv[1]["ms"])
+            name, r = dom
+            tfl = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                                "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(r["launches"], 1), 4),
+                                "share_of_kernel_time": round(r["ms"] / tot, 4) if tot else None}
+            line["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None,
+                                   "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None}
+                               for k, v in sorted(res.items(), key=lambda kv: -kv[1]["ms"])}
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            try:
+                v, dt = cpu_baseline(cfg, S, F, threads)
+                line["cpu_baseline"] = {"value": round(v, 5), "unit": "pairs/s", "cores": threads, "kind": "port",
+                                        "sample": f"1 video ({F} tiles @{S}^2, N={seq_len}) = half a pair, one oracle forward "
+                                                  f"in bf16 incl. the reference's unused LM-head GEMM, {dt:.1f}s, no warm-up"}
+            except Exception as e:  # the baseline is informational; never lose the GPU number over it
+                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -322,12 +322,13 @@ class InternVLChatRewardModeling(nn.Module):
 
     # -- construction helpers -------------------------------------------------------------------
     @classmethod
-    def from_config(cls, config, dtype=torch.float32) -> "InternVLChatRewardModeling":
-        """Uninitialised parameters of the right shapes in ``dtype`` (fill with ``load_state_dict``)."""
+    def from_config(cls, config, dtype=torch.float32, device=None) -> "InternVLChatRewardModeling":
+        """Uninitialised parameters of the right shapes in ``dtype`` on ``device`` (fill with ``load_state_dict``)."""
         prev = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:
-            return cls("<config>", config, base_model=InternVLChatModel(config))
+            with torch.device(device if device is not None else "cpu"):
+                return cls("<config>", config, base_model=InternVLChatModel(config))
         finally:
             torch.set_default_dtype(prev)
 

