@@ -49,7 +49,11 @@ def load_reference():
             sys.path.insert(0, p)
     if not dist.is_initialized():  # modeling_internvl_chat.py:172 calls get_rank()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         dist.init_process_group("gloo", world_size=1, rank=0)
     import moe_reward  # noqa: E402  (the reference's module)
     from internvl2 import InternVLChatConfig

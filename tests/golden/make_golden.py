@@ -114,7 +114,7 @@ def gen_tiny():
                                                   for a, b, c, d in vids]))
         print("tiny case", name, "score", ref["score"].tolist(), "fp32", f32["score"].tolist())
     np.savez_compressed(os.path.join(HERE, "tiny.npz"), **arrays)
-    json.dump(dict(cases=cases), open(os.path.join(HERE, "tiny.json"), "w"), indent=1)
+    json.dump(dict(cases=cases, cpu_threads=torch.get_num_threads()), open(os.path.join(HERE, "tiny.json"), "w"), indent=1)
 
 
 def gen_full(tag: str, S: int, n_videos: int, wseed: int, pixel_seed: int, n_tiles: int = 8, check_oracle: int = 1):
@@ -188,6 +188,7 @@ def gen_rankset(tag: str, S: int, pairs: int, wseed: int, pixel_seed: int, fp32_
             np.savez_compressed(path, ref_bf16=out[:p + 1], ref_fp32=out32[:p + 1])
             json.dump(dict(kind="2b", image_size=S, weight_seed=wseed, pixel_seed=pixel_seed, pairs=p + 1,
                            n_tiles=n_tiles, caption_seed_base=1000, fp32_every=fp32_every,
+                           cpu_threads=torch.get_num_threads(),
                            layout="[pair, video, (score, aspect_scores[5], rewards[28])]"),
                       open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
 

@@ -1,0 +1,296 @@
+"""CPU: host-side logic of the drop-in boundary (no GPU, no compute calls into the library)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import mj_video_amd
+from mj_video_amd import _lib, chat_input, configuration as C, harness, parallel, synth, video
+from mj_video_amd.modeling import CustomOutput, InternVLChatRewardModeling, find_token_for_gating
+from util import ROOT, make_cfg
+
+
+# ------------------------------------------------------------------------------------------- C ABI
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    path = _lib.build_library()
+    header = open(os.path.join(ROOT, "include", "mjv.h")).read()
+    declared = set(re.findall(r"\b(mjv_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mjv_abi_version() == 1
+    assert lib.mjv_arch() == b"gfx950"
+    assert os.path.dirname(path).endswith("mj-video_amd")  # in-tree, so the driver sees it loaded
+
+
+def test_library_rejects_bad_arguments_without_a_gpu():
+    lib = _lib.load_library()
+    d = _lib.GemmDesc()
+    assert lib.mjv_gemm_bf16(ctypes.byref(d), None) == -1
+    assert b"null pointer" in lib.mjv_last_error()
+    d.A = d.W = d.C = 1024
+    d.M, d.N, d.K = 4, 8, 100
+    d.lda = d.ldw = 104
+    d.ldc = 8
+    assert lib.mjv_gemm_bf16(ctypes.byref(d), None) == -1
+    assert b"multiple of 64" in lib.mjv_last_error()
+    a = _lib.AttnDesc()
+    a.Q = a.K = a.V = a.O = a.cu_seqlens = 1024
+    a.head_dim = 96
+    assert lib.mjv_attention_bf16(ctypes.byref(a), None) == -1
+    assert b"head_dim" in lib.mjv_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MjvLibraryError, match="no CPU fallback"):
+        _lib.load_library()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mj-video_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+# ------------------------------------------------------------------------------------- prompt logic
+class StubTokenizer:
+    """duck-typed tokenizer: special tokens are single ids, every other character is one id"""
+    special = {"<|im_start|>": 92543, "<|im_end|>": 92542, "<img>": 92544, "</img>": 92545, "<IMG_CONTEXT>": 92546}
+
+    def convert_tokens_to_ids(self, t):
+        return self.special[t]
+
+    def __call__(self, text, return_tensors="pt"):
+        ids, i = [1], 0
+        while i < len(text):
+            for tok, tid in self.special.items():
+                if text.startswith(tok, i):
+                    ids.append(tid)
+                    i += len(tok)
+                    break
+            else:
+                if text.startswith("assistant", i):      # real tokenizer: 'assistant' -> 525, 11353
+                    ids += [525, 11353]
+                    i += 9
+                elif text[i] == "\n":
+                    ids.append(364)
+                    i += 1
+                else:
+                    ids.append(1000 + (ord(text[i]) % 50000))
+                    i += 1
+        t = torch.tensor([ids])
+        return {"input_ids": t, "attention_mask": torch.ones_like(t)}
+
+
+SYSTEM = ("<|im_start|>system\n你是由上海人工智能实验室联合商汤科技开发的书生多模态大模型，英文名叫InternVL, "
+          "是一个有用无害的人工智能助手。<|im_end|>")
+
+
+def test_prompt_default_only_first_image_placeholder_is_expanded():
+    cfg = make_cfg("2b", 448)
+    F = 8
+    q = chat_input.video_prefix(F) + "a cat"
+    s = chat_input.build_query(cfg, q, n_tiles=F)
+    ctx = "<IMG_CONTEXT>" * (256 * F)
+    expect = (SYSTEM + "<|im_start|>user\nFrame1: <img>" + ctx + "</img>\n" +
+              "".join(f"Frame{i}: <image>\n" for i in range(2, F + 1)) + "a cat<|im_end|><|im_start|>assistant\n")
+    assert s == expect
+
+
+def test_prompt_interleaved_and_prefix_rules():
+    cfg = make_cfg("2b", 224)
+    s = chat_input.build_query(cfg, chat_input.video_prefix(3) + "x", n_tiles=3, num_patches_list=[1, 1, 1])
+    assert s.count("<IMG_CONTEXT>") == 3 * 64 and s.count("<img>") == 3 and "<image>" not in s
+    s2 = chat_input.build_query(cfg, "describe", n_tiles=2)
+    assert "user\n<img>" in s2 and s2.count("<IMG_CONTEXT>") == 128  # '<image>\n' is prepended when missing
+    with pytest.raises(AssertionError):
+        chat_input.build_query(cfg, "x", n_tiles=3, num_patches_list=[1, 1])
+
+
+def test_prepare_chat_input_side_effects_and_shapes():
+    cfg = make_cfg("2b", 448)
+    gen = {"max_new_tokens": 8}
+    px = torch.zeros(8, 3, 448, 448)
+    ids, mask = chat_input.prepare_chat_input(cfg, StubTokenizer(), px, chat_input.video_prefix(8) + "hi", gen)
+    assert gen["eos_token_id"] == 92542
+    assert ids.shape == mask.shape and ids.shape[0] == 1
+    assert int((ids == 92546).sum()) == 2048
+    assert find_token_for_gating(ids[0].tolist()) == ids.shape[1] - 5
+
+
+def test_find_token_for_gating_matches_reference_semantics():
+    pat = [92542, 92543, 525, 11353, 364]
+    assert find_token_for_gating([7] + pat + [9] + pat) == 7
+    assert find_token_for_gating(pat) == 0
+    with pytest.raises(ValueError, match="Token pattern not found in the list."):
+        find_token_for_gating([1, 2, 3])
+    with pytest.raises(ValueError):
+        find_token_for_gating(pat[:-1])
+
+
+# ------------------------------------------------------------------------------------------ configs
+def test_config_roundtrip_and_kwargs_override(tmp_path):
+    cfg = make_cfg("2b", 448)
+    cfg.save_pretrained(str(tmp_path))
+    re_cfg = C.InternVLChatRewardModelingConfig.from_pretrained(str(tmp_path), num_objectives=10, gating_temperature=2.0)
+    assert re_cfg.num_objectives == 10 and re_cfg.gating_temperature == 2.0 and re_cfg.num_aspects == 5
+    assert re_cfg.aspect2criteria[3] == [16, 17, 18, 19, 20, 21, 22]
+    assert re_cfg.llm_config.hidden_size == 2048 and re_cfg.vision_config.patch_size == 14
+    assert re_cfg.llm_config.rope_scaling == {"type": "dynamic", "factor": 2.0}
+    d = re_cfg.to_dict()
+    assert d["model_type"] == "internvl_chat" and d["llm_config"]["num_key_value_heads"] == 8
+    with pytest.raises(ValueError, match="rope_scaling"):
+        C.InternLM2Config(rope_scaling={"type": "yarn", "factor": 2.0})
+    with pytest.raises(ValueError, match="Unsupported architecture"):
+        C.InternVLChatConfig(llm_config={"architectures": ["Phi3ForCausalLM"]})
+    with pytest.raises(FileNotFoundError):
+        C.InternVLChatRewardModelingConfig.from_pretrained(str(tmp_path / "missing"))
+
+
+def test_state_dict_layout_and_param_count():
+    cfg = make_cfg("tiny", 56)
+    model = InternVLChatRewardModeling.from_config(cfg)
+    keys = set(model.state_dict().keys())
+    spec = {k: s for k, s, _ in synth.state_dict_spec(cfg)}
+    assert keys == set(spec)
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == spec[k], k
+    assert "model.mlp1.3.weight" in keys and "model.mlp1.2.weight" not in keys
+    assert "model.language_model.output.weight" in keys
+    full = make_cfg("2b", 448)
+    n = sum(int(np.prod(s)) for k, s, _ in synth.state_dict_spec(full)
+            if k.startswith("model."))
+    assert n == 2_205_754_368  # matches the published 2.21 B
+    with pytest.raises(AssertionError):
+        bad = make_cfg("tiny", 56)
+        bad.aspect2criteria = {0: [0, 1], 1: [1, 2]}
+        InternVLChatRewardModeling.from_config(bad)
+
+
+def test_model_refuses_cpu_and_non_bf16():
+    cfg = make_cfg("tiny", 56)
+    model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16)
+    model.load_state_dict(synth.synth_state_dict(cfg, seed=1), strict=True)
+    model.model.img_context_token_id = synth.IMG_CONTEXT_ID
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        model.forward(torch.zeros(2, 3, 56, 56, dtype=torch.bfloat16), synth.synth_input_ids(8, 1), None)
+
+
+def test_analyse_ids_packing():
+    cfg = make_cfg("tiny", 56)
+    model = InternVLChatRewardModeling.from_config(cfg)
+    model.config.pad_token_id = synth.PAD_ID
+    model.model.img_context_token_id = synth.IMG_CONTEXT_ID
+    a, b = synth.synth_input_ids(16, 1), synth.synth_input_ids(8, 2)
+    ids, mask = synth.pad_batch([a, b])
+    info = model._analyse_ids(ids, mask, 6)
+    assert info["cu"].tolist() == [0, a.shape[1], a.shape[1] + b.shape[1]]
+    assert info["sel_rows"].tolist() == [a.shape[1] - 1, a.shape[1] + b.shape[1] - 1, a.shape[1] - 5, a.shape[1] + b.shape[1] - 5]
+    assert (info["ids"][info["img_rows"]] == synth.IMG_CONTEXT_ID).all() and info["img_rows"].size == 24
+    assert info["positions"][a.shape[1]] == 0
+    with pytest.raises(ValueError, match="IMG_CONTEXT"):
+        model._analyse_ids(ids, mask, 5)
+    left = torch.flip(mask, dims=[1])
+    with pytest.raises(NotImplementedError, match="right-padded"):
+        model._analyse_ids(ids, left, 6)
+    model.model.img_context_token_id = None
+    with pytest.raises(ValueError, match="img_context_token_id"):
+        model._analyse_ids(ids, mask, 6)
+
+
+def test_custom_output_access():
+    o = CustomOutput(rewards=torch.ones(1), score=torch.zeros(1))
+    assert o["score"] is o.score and o[0] is o.rewards and o.keys() == ["rewards", "score"]
+
+
+# --------------------------------------------------------------------------------- synthetic inputs
+def test_synth_is_deterministic_and_layout_is_right():
+    cfg = make_cfg("tiny", 56)
+    a = synth.synth_state_dict(cfg, seed=5)
+    b = synth.synth_state_dict(cfg, seed=5)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = synth.synth_state_dict(cfg, seed=6)
+    assert not torch.equal(a["regression_layer.weight"], c["regression_layer.weight"])
+    # pinned values: any change to the generator silently invalidates every golden vector
+    w = synth.synth_state_dict(cfg, seed=11, dtype=torch.float32)["regression_layer.weight"]
+    assert abs(float(w[0, 0]) - float(synth._normal(11, "regression_layer.weight", (28, 256), 0.05)[0, 0])) == 0
+    ids = synth.synth_input_ids(2048, 3)
+    assert ids.shape == (1, 2186) and ids[0, 0] == 1 and ids[0, -5:].tolist() == list(synth.GATING_PATTERN)
+    assert int((ids == synth.IMG_CONTEXT_ID).sum()) == 2048 and int((ids == synth.PAD_ID).sum()) == 0
+    il = synth.synth_input_ids(32, 3, interleave_frames=4)
+    runs = (il[0] == synth.IMG_CONTEXT_ID).int().diff().abs().sum().item()
+    assert runs == 8  # four separate runs of context tokens
+    px = synth.synth_pixel_values(1, 2, 3, 56)
+    assert px.shape == (3, 3, 56, 56) and px.dtype == torch.bfloat16 and torch.equal(px, synth.synth_pixel_values(1, 2, 3, 56))
+
+
+# -------------------------------------------------------------------------------------- load_video
+def test_frame_index_and_tile_grid_pinned_values():
+    """values captured from the reference's own functions"""
+    assert video.get_index(None, 30.0, 99, 0, 8).tolist() == [0, 12, 24, 37, 49, 61, 74, 86]
+    assert video.get_index(None, 30.0, 48, 0, 16).tolist() == [3 * i for i in range(16)]
+    assert video.get_index((1.0, 2.0), 10.0, 99, 0, 5).tolist() == [10, 12, 14, 16, 18]
+    from PIL import Image
+
+    def ntiles(w, h, max_num):
+        return len(video.dynamic_preprocess(Image.new("RGB", (w, h)), image_size=448, use_thumbnail=True, max_num=max_num))
+
+    assert all(ntiles(w, h, 1) == 1 for w, h in [(512, 512), (1280, 720), (720, 1280)])
+    assert ntiles(512, 512, 6) == 1 and ntiles(1024, 1024, 6) == 5
+    assert [ntiles(w, h, 6) for w, h in [(1280, 720), (1920, 1080), (854, 480), (720, 1280)]] == [3, 3, 3, 3]
+    assert ntiles(1344, 896, 6) == 7
+
+
+def test_load_frames_normalisation_and_order():
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, size=(448, 896, 3), dtype=np.uint8) for _ in range(2)]
+    pv, counts = video.load_frames(frames, input_size=448, max_num=2)
+    assert counts == [3, 3] and pv.shape == (6, 3, 448, 448) and pv.dtype == torch.float32
+    left = torch.from_numpy(frames[0][:, :448].astype(np.float32) / 255.0).permute(2, 0, 1)
+    mean = torch.tensor(video.IMAGENET_MEAN).view(3, 1, 1)
+    std = torch.tensor(video.IMAGENET_STD).view(3, 1, 1)
+    assert torch.allclose(pv[0], (left - mean) / std, atol=1e-6)  # 2x1 grid at native size: first tile = left half
+    pv1, c1 = video.load_frames(frames, input_size=448, max_num=1)
+    assert c1 == [1, 1] and pv1.shape == (2, 3, 448, 448)
+    with pytest.raises(RuntimeError, match="no network"):
+        video.load_video("http://example.com/x.mp4")
+
+
+# ----------------------------------------------------------------------------------------- harness
+def test_preference_protocol():
+    votes = [("rightvote", 0.1, 0.5), ("rightvote", 0.5, 0.1), ("leftvote", 0.3, -0.2), ("bothbad_vote", -1.0, -0.1),
+             ("bothbad_vote", -1.0, 0.1), ("tievote", 0.2, 0.3), ("tievote", 0.2, 0.0), ("leftvote", 0.1, 0.1)]
+    c = harness.evaluate_votes(votes)
+    assert (c.prefer_truth, c.prefer_total, c.truth, c.total) == (2, 4, 4, 8)
+    assert c.prefer_acc == 0.5 and c.acc == 0.5
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 64):
+        for w in (1, 2, 8):
+            spans = [parallel.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_dropin_import_paths():
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        m = importlib.import_module("model")
+        assert m.InternVLChatRewardModelingConfig is C.InternVLChatRewardModelingConfig
+        assert m.prepare_chat_input is chat_input.prepare_chat_input
+        dp = importlib.import_module("data_processor")
+        assert dp.load_video is video.load_video
+    finally:
+        sys.path.remove(os.path.join(ROOT, "scripts"))
