@@ -77,6 +77,9 @@ typedef struct mjv_gemm_desc {
 } mjv_gemm_desc;
 
 int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);
+/* tile selection: 0 = automatic (256x256 8-wave kernel for M >= 512 and N >= 256, else 128x128), 128 or 256 force
+ * one kernel (used by the parity tests to cover both on every shape). */
+int mjv_gemm_set_tile(int32_t tile);
 
 /* ---------------------------------------------------------------------------------------------
  * Flash-style attention over packed variable-length sequences (no N x N scores in HBM).

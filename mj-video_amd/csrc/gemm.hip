@@ -1,23 +1,29 @@
 // bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue(A[M,K] @ W[N,K]^T), fp32 accumulate.
 //
-// Structure (cdna_hip_programming.md §5): 128x128 output tile per 256-thread workgroup (4 waves, 2x2,
-// 64x64 per wave as 4x4 MFMA 16x16x32 tiles), BK = 64, both operand tiles staged global -> LDS with
-// 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per K tile.  The LDS image is
-// lane-linear (a DMA requirement), so the bank-conflict swizzle is applied on the per-lane SOURCE address
-// (16-byte chunk c of row r is stored at chunk c ^ (r & 7)) and undone on the ds_read_b128 side.
+// Two kernels share the operand layout, the LDS image and the epilogues:
 //
-// Operand roles are swapped w.r.t. the textbook: the WEIGHT tile is the MFMA A operand and the
-// ACTIVATION tile the B operand, so each lane ends up with 4 consecutive output COLUMNS of one output
-// row (D row = n, D col = m) and the epilogue stores 8 bytes per lane instead of 4 scattered bf16.
+//  * gemm256_kernel - the production shape.  256x256x64 tile, 512 threads (8 waves as 2(M) x 4(N), 128x64 per
+//    wave, 128 accumulator VGPRs), 128 KiB LDS = 2 K-tiles x 4 half-tiles (128 rows x 64 k) of 16 KiB.  Each
+//    K-tile runs as 4 phases {ds_read a register sub-tile | issue ONE half-tile of LDS-DMA two K-tiles ahead |
+//    barrier | 16 MFMA | barrier}; DMA stays in flight across barriers behind a COUNTED s_waitcnt vmcnt(4) once per
+//    K-tile (never 0 in the steady state), raw s_barrier only.  The two M-groups of waves run one barrier apart,
+//    so on every SIMD one wave is in its MFMA segment while its partner reads LDS / issues DMA
+//    (cdna_hip_programming.md §5 "8-phase template", MI355X_MICROARCH.md "Two waves per SIMD").
+//  * gemm128_kernel - 128x128x64 tile, 256 threads, double-buffered, one barrier per K-tile; used for small
+//    problems (tiny configs, the M = batch gating layers) where a 256^2 tile would be mostly padding.
+//
+// Operand staging is 16-byte LDS-DMA (global_load_lds_dwordx4).  The LDS image must be lane-linear, so the
+// bank-conflict swizzle is applied on the per-lane SOURCE address (16-B chunk c of row r is stored at chunk
+// c ^ (r & 7)) and undone on the ds_read_b128 side; reads are conflict-free.
+//
+// Operand roles are swapped w.r.t. the textbook: the WEIGHT tile is the MFMA A operand and the ACTIVATION tile
+// the B operand, so each lane ends up with 4 consecutive output COLUMNS of one output row (D row = n, D col = m)
+// and the epilogue moves 8 bytes per lane per access.
 //
 // Epilogues reproduce the reference's bf16 op boundaries (one rounding per torch op).
 #include "mjv_common.h"
 
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
-constexpr int LDS_BYTES = 4 * TILE_BYTES;
 
 struct GemmArgs {
   const u16* A; long lda;
@@ -33,12 +39,103 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-MJV_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf with |error| < 1.2e-7 (Abramowitz-Stegun 7.1.26 refined is not enough; use the W. J. Cody-style
+// rational split cheap enough for an epilogue): for the bf16 output of GELU 1e-6 absolute is far below half an ulp.
+MJV_DEV float erf_fast(float x) {
+  // erf(x) = sign(x) * (1 - t * exp(-x^2 + P(t))),  t = 1 / (1 + 0.5 |x|)   (Numerical Recipes erfc Chebyshev fit,
+  // fractional error < 1.2e-7 everywhere)
+  const float z = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.5f * z);
+  float p = 0.17087277f;
+  p = fmaf(p, t, -0.82215223f);
+  p = fmaf(p, t, 1.48851587f);
+  p = fmaf(p, t, -1.13520398f);
+  p = fmaf(p, t, 0.27886807f);
+  p = fmaf(p, t, -0.18628806f);
+  p = fmaf(p, t, 0.09678418f);
+  p = fmaf(p, t, 0.37409196f);
+  p = fmaf(p, t, 1.00002368f);
+  p = fmaf(p, t, -1.26551223f);
+  const float r = t * __expf(fmaf(-z, z, p));
+  const float e = 1.0f - r;
+  return x >= 0.f ? e : -e;
+}
+MJV_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 MJV_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
 
-// stage one 128 x 64 bf16 tile: 16 DMA pieces of 8 rows x 128 B; wave w issues pieces 4w .. 4w+3
-MJV_DEV void stage_tile(const u16* __restrict__ src, long ld, int row0, int max_row, int k0, char* lds_tile,
-                        int wave, int lane) {
+MJV_DEV long out_row_of(const GemmArgs& p, int m) {
+  if (p.out_rows) return p.out_rows[m];
+  if (p.out_group > 0) {
+    const int gq = m / p.out_group;
+    return (long)gq * (p.out_group + p.out_pad) + p.out_pad + (m - gq * p.out_group);
+  }
+  return m;
+}
+
+// one 16x16 accumulator fragment: this lane holds output row m, columns n .. n+3
+template <int EPI>
+MJV_DEV void store_frag(const GemmArgs& p, const f32x4& acc, int m, long orow, int n) {
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (p.bias) {
+    const u32x2 bb = *(const u32x2*)(p.bias + n);
+    v[0] += __uint_as_float(bb[0] << 16);
+    v[1] += __uint_as_float(bb[0] & 0xffff0000u);
+    v[2] += __uint_as_float(bb[1] << 16);
+    v[3] += __uint_as_float(bb[1] & 0xffff0000u);
+  }
+  if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(rbf(v[r]));
+  } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  } else if constexpr (EPI == MJV_EPI_SCALE_RES) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+    if (p.scale) {
+      const u32x2 ss = *(const u32x2*)(p.scale + n);
+      v[0] = rbf(v[0] * __uint_as_float(ss[0] << 16));
+      v[1] = rbf(v[1] * __uint_as_float(ss[0] & 0xffff0000u));
+      v[2] = rbf(v[2] * __uint_as_float(ss[1] << 16));
+      v[3] = rbf(v[3] * __uint_as_float(ss[1] & 0xffff0000u));
+    }
+    const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;
+    const u32x2 rr = *(const u32x2*)(p.res + rrow * p.ldr + n);
+    v[0] += __uint_as_float(rr[0] << 16);
+    v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+    v[2] += __uint_as_float(rr[1] << 16);
+    v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+  }
+  const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+  *(u32x2*)(p.C + orow * p.ldc + n) = o;
+}
+
+// SiLU-mul: gate fragment (weight rows n..n+3 of a w1 block) and the matching up fragment (w3 block)
+MJV_DEV void store_silu(const GemmArgs& p, const f32x4& g, const f32x4& u, long orow, int oc) {
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = rbf(silu(rbf(g[r]))) * rbf(u[r]);
+  const u32x2 v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+  *(u32x2*)(p.C + orow * p.ldc + oc) = v;
+}
+
+MJV_DEV void tile_of_block(const GemmArgs& p, int& tm, int& tn) {
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a contiguous
+  // range of the (m-major, n-minor) tile list: its tiles then share activation panels through its own L2.
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+  const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+  tm = tile / p.tiles_n;
+  tn = tile - tm * p.tiles_n;
+}
+
+// ============================================================================================ 128 x 128
+namespace t128 {
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;
+constexpr int LDS_BYTES = 4 * TILE_BYTES;
+
+MJV_DEV void stage_tile(const u16* __restrict__ src, long ld, int row0, int max_row, int k0, char* lds_tile, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int piece = wave * 4 + i;
@@ -53,19 +150,13 @@ MJV_DEV void stage_tile(const u16* __restrict__ src, long ld, int row0, int max_
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
-
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a
-  // contiguous range of the (m-major, n-minor) tile list: its tiles then share A panels through its L2.
-  const int nwg = gridDim.x;
-  const int b = blockIdx.x;
-  const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-  const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  int tm, tn;
+  tile_of_block(p, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4 acc[4][4];
@@ -113,93 +204,216 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds, for tile (i, j), rows n = 4*l4 .. 4*l4+3 (registers) of column m = l15
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + l15;
     if (m >= p.M) continue;
-    long orow = m;
-    if (p.out_rows) {
-      orow = p.out_rows[m];
-    } else if (p.out_group > 0) {
-      const int gq = m / p.out_group;
-      orow = (long)gq * (p.out_group + p.out_pad) + p.out_pad + (m - gq * p.out_group);
-    }
+    const long orow = out_row_of(p, m);
     if constexpr (EPI == MJV_EPI_SILU_MUL) {
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {
-        const int n = n0 + wn * 64 + j * 16 + l4 * 4;  // row of the interleaved weight (gate block)
+        const int n = n0 + wn * 64 + j * 16 + l4 * 4;
         if (n >= p.N) continue;
-        const int oc = (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4;
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float gte = rbf(acc[i][j][r]);
-          const float up = rbf(acc[i][j + 1][r]);
-          o[r] = rbf(silu(gte)) * up;
-        }
-        u32x2 v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-        *(u32x2*)(p.C + orow * p.ldc + oc) = v;
+        store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4);
       }
     } else {
-      long rrow = m;
-      if (p.res_mod > 0) rrow = p.res_off + (m % p.res_mod);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + l4 * 4;
         if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-        if (p.bias) {
-          const u32x2 bb = *(const u32x2*)(p.bias + n);
-          v[0] += __uint_as_float(bb[0] << 16);
-          v[1] += __uint_as_float(bb[0] & 0xffff0000u);
-          v[2] += __uint_as_float(bb[1] << 16);
-          v[3] += __uint_as_float(bb[1] & 0xffff0000u);
-        }
-        if constexpr (EPI == MJV_EPI_BIAS_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(rbf(v[r]));
-        } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        } else if constexpr (EPI == MJV_EPI_SCALE_RES) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-          if (p.scale) {
-            const u32x2 ss = *(const u32x2*)(p.scale + n);
-            v[0] = rbf(v[0] * __uint_as_float(ss[0] << 16));
-            v[1] = rbf(v[1] * __uint_as_float(ss[0] & 0xffff0000u));
-            v[2] = rbf(v[2] * __uint_as_float(ss[1] << 16));
-            v[3] = rbf(v[3] * __uint_as_float(ss[1] & 0xffff0000u));
-          }
-          const u32x2 rr = *(const u32x2*)(p.res + rrow * p.ldr + n);
-          v[0] += __uint_as_float(rr[0] << 16);
-          v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-          v[2] += __uint_as_float(rr[1] << 16);
-          v[3] += __uint_as_float(rr[1] & 0xffff0000u);
-        }
-        u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *(u32x2*)(p.C + orow * p.ldc + n) = o;
+        store_frag<EPI>(p, acc[i][j], m, orow, n);
       }
     }
   }
 }
+}  // namespace t128
+
+// ============================================================================================ 256 x 256
+namespace t256 {
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB: 128 rows x 64 k
+constexpr int LDS_BYTES = 8 * HALF_BYTES;  // 2 K-tiles x {W0, W1, A0, A1}
+
+// stage half-tile number n (order per K-tile: W rows 0-127, W rows 128-255, A rows 0-127, A rows 128-255)
+MJV_DEV void stage_half(const GemmArgs& p, int n, int nk, int m0, int n0, char* smem, int wave, int lane) {
+  const int t = n >> 2, which = n & 3;
+  if (t >= nk) return;
+  const bool is_w = which < 2;
+  const u16* __restrict__ src = is_w ? p.W : p.A;
+  const long ld = is_w ? p.ldw : p.lda;
+  const int row0 = (is_w ? n0 : m0) + (which & 1) * 128;
+  const int max_row = (is_w ? p.N : p.M) - 1;
+  char* dst = smem + ((t & 1) * 4 + which) * HALF_BYTES;
+  const int k0 = t * BK;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = wave * 2 + i;
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    int gr = row0 + r;
+    gr = gr < max_row ? gr : max_row;
+    const u16* g = src + (long)gr * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+  }
+}
+
+#define MJV_BARRIER()                      \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
 
 template <int EPI>
-int launch(const GemmArgs& a, hipStream_t s) {
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;   // wave owns output rows m: wr*128.., columns n: wc*64..
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int tm, tn;
+  tile_of_block(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.K / BK;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane LDS byte offsets inside a half-tile (row pitch 128 B, chunk swizzle ^ (row & 7)); the row's low 3
+  // bits are l15 & 7 for every fragment, so one XOR term serves all of them
+  const int sw = l15 & 7;
+  int a_off[2], w_off[2];  // [kk]
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    a_off[kk] = l15 * 128 + (((kk * 4 + l4) ^ sw) << 4);
+    w_off[kk] = ((wc & 1) * 64 + l15) * 128 + (((kk * 4 + l4) ^ sw) << 4);
+  }
+  const int a_half = 2 + wr;   // this wave's activation half-tile index within a K-tile
+  const int w_half = wc >> 1;  // this wave's weight half-tile index
+
+  // ---- prologue: K-tile 0 completely, W halves of K-tile 1
+#pragma unroll
+  for (int n = 0; n < 6; ++n) stage_half(p, n, nk, m0, n0, smem, wave, lane);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MJV_BARRIER();
+  if (wr == 1) MJV_BARRIER();  // stagger the second M-group by one barrier
+
+  bf16x8 af[4][2], wf[2][2][2];  // af[i][kk]; wf[ns][j][kk]
+
+#define MJV_LOAD_A(MS)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+      af[i][kk] = *(const bf16x8*)(abase + ((MS) * 64 + i * 16) * 128 + a_off[kk]);
+#define MJV_LOAD_W(NS)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+      wf[NS][j][kk] = *(const bf16x8*)(wbase + ((NS) * 32 + j * 16) * 128 + w_off[kk]);
+#define MJV_MFMA(MS, NS)                                                                                  \
+  __builtin_amdgcn_s_setprio(1);                                                                          \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)          \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(MS) * 4 + i][(NS) * 2 + j] =                     \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NS][j][kk], af[i][kk], acc[(MS) * 4 + i][(NS) * 2 + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+
+  for (int t = 0; t < nk; ++t) {
+    const char* abase = smem + ((t & 1) * 4 + a_half) * HALF_BYTES;
+    const char* wbase = smem + ((t & 1) * 4 + w_half) * HALF_BYTES;
+    const int g = 4 * t;
+    // phase 1: quadrant (0,0)
+    MJV_LOAD_W(0)
+    MJV_LOAD_A(0)
+    stage_half(p, g + 6, nk, m0, n0, smem, wave, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MJV_BARRIER();
+    MJV_MFMA(0, 0)
+    MJV_BARRIER();
+    // phase 2: quadrant (0,1)
+    MJV_LOAD_W(1)
+    stage_half(p, g + 7, nk, m0, n0, smem, wave, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MJV_BARRIER();
+    MJV_MFMA(0, 1)
+    MJV_BARRIER();
+    // phase 3: quadrant (1,1)
+    MJV_LOAD_A(1)
+    stage_half(p, g + 8, nk, m0, n0, smem, wave, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MJV_BARRIER();
+    MJV_MFMA(1, 1)
+    MJV_BARRIER();
+    // phase 4: quadrant (1,0); retire K-tile t+1 (everything but the 2 half-tiles of t+2 issued last)
+    stage_half(p, g + 9, nk, m0, n0, smem, wave, lane);
+    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MJV_BARRIER();
+    MJV_MFMA(1, 0)
+    MJV_BARRIER();
+  }
+  if (wr == 0) MJV_BARRIER();  // matches the stagger barrier of the second M-group
+#undef MJV_LOAD_A
+#undef MJV_LOAD_W
+#undef MJV_MFMA
+
+  // ---- epilogue: acc[i][j] = rows n (4 per lane) x column m
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + l15;
+    if (m >= p.M) continue;
+    const long orow = out_row_of(p, m);
+    if constexpr (EPI == MJV_EPI_SILU_MUL) {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int n = n0 + wc * 64 + j * 16 + l4 * 4;
+        if (n >= p.N) continue;
+        store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wc * 64) / 2 + (j / 2) * 16 + l4 * 4);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + l4 * 4;
+        if (n >= p.N) continue;
+        store_frag<EPI>(p, acc[i][j], m, orow, n);
+      }
+    }
+  }
+}
+}  // namespace t256
+
+int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
+
+template <int EPI>
+int launch(GemmArgs a, hipStream_t s, bool big) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     attr_done = true;
   }
-  const int grid = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(grid), dim3(256), LDS_BYTES, s, a);
+  if (big) {
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    hipLaunchKernelGGL(t256::gemm256_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+  } else {
+    a.tiles_m = (a.M + 127) / 128;
+    a.tiles_n = (a.N + 127) / 128;
+    hipLaunchKernelGGL(t128::gemm128_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), t128::LDS_BYTES, s, a);
+  }
   return mjv_check_launch("gemm_bf16");
 }
 
 }  // namespace
+
+extern "C" int mjv_gemm_set_tile(int32_t tile) {
+  if (tile != 0 && tile != 128 && tile != 256) {
+    mjv_set_error("gemm_set_tile: %d not in {0,128,256}", tile);
+    return MJV_E_ARG;
+  }
+  g_force_tile = tile;
+  return MJV_OK;
+}
 
 extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   MJV_REQUIRE(d && d->A && d->W && d->C, "gemm: null pointer");
@@ -221,17 +435,17 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.bias = d->bias; a.scale = d->scale; a.res = d->res; a.ldr = d->ldr;
   a.res_mod = d->res_mod; a.res_off = d->res_off; a.out_group = d->out_group; a.out_pad = d->out_pad;
   a.out_rows = d->out_rows;
-  a.tiles_m = (d->M + BM - 1) / BM;
-  a.tiles_n = (d->N + BN - 1) / BN;
+  a.tiles_m = a.tiles_n = 0;
+  const bool big = g_force_tile ? g_force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * d->M * (double)d->N * d->K;
   const double bytes = 2.0 * ((double)d->M * d->K + (double)d->N * d->K + (double)d->M * d->N);
   switch (d->epilogue) {
-    case MJV_EPI_BIAS: { MjvProfScope ps("gemm_bias", s, flops, bytes); return launch<MJV_EPI_BIAS>(a, s); }
-    case MJV_EPI_BIAS_GELU: { MjvProfScope ps("gemm_bias_gelu", s, flops, bytes); return launch<MJV_EPI_BIAS_GELU>(a, s); }
-    case MJV_EPI_BIAS_RELU: { MjvProfScope ps("gemm_bias_relu", s, flops, bytes); return launch<MJV_EPI_BIAS_RELU>(a, s); }
-    case MJV_EPI_SCALE_RES: { MjvProfScope ps("gemm_scale_res", s, flops, bytes); return launch<MJV_EPI_SCALE_RES>(a, s); }
-    case MJV_EPI_SILU_MUL: { MjvProfScope ps("gemm_silu_mul", s, flops, bytes); return launch<MJV_EPI_SILU_MUL>(a, s); }
+    case MJV_EPI_BIAS: { MjvProfScope ps("gemm_bias", s, flops, bytes); return launch<MJV_EPI_BIAS>(a, s, big); }
+    case MJV_EPI_BIAS_GELU: { MjvProfScope ps("gemm_bias_gelu", s, flops, bytes); return launch<MJV_EPI_BIAS_GELU>(a, s, big); }
+    case MJV_EPI_BIAS_RELU: { MjvProfScope ps("gemm_bias_relu", s, flops, bytes); return launch<MJV_EPI_BIAS_RELU>(a, s, big); }
+    case MJV_EPI_SCALE_RES: { MjvProfScope ps("gemm_scale_res", s, flops, bytes); return launch<MJV_EPI_SCALE_RES>(a, s, big); }
+    case MJV_EPI_SILU_MUL: { MjvProfScope ps("gemm_silu_mul", s, flops, bytes); return launch<MJV_EPI_SILU_MUL>(a, s, big); }
     default: mjv_set_error("gemm: unknown epilogue %d", d->epilogue); return MJV_E_ARG;
   }
 }

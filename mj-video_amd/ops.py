@@ -59,6 +59,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     return out
 
 
+def gemm_set_tile(tile: int) -> None:
+    """0 = automatic choice, 128 / 256 = force that tile kernel (parity tests)."""
+    check(load_library().mjv_gemm_set_tile(tile), "mjv_gemm_set_tile")
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, cu_seqlens: torch.Tensor,
               max_seqlen: int, n_heads: int, kv_group: int, head_dim: int, causal: bool, scale: float,
               score_round_mode: int, q_head_stride: Optional[int] = None, k_head_stride: Optional[int] = None,

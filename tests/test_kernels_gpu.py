@@ -34,8 +34,17 @@ def assert_close_bf16(out, ref, max_ulps, frac_exact=0.0, atol=0.0, what=""):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=[128, 256])
+def tile(request, cuda):
+    """run every GEMM test on both tile kernels (the automatic choice would hide the 256^2 kernel at test sizes)"""
+    from mj_video_amd import ops
+    ops.gemm_set_tile(request.param)
+    yield request.param
+    ops.gemm_set_tile(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 128), (1, 256, 256), (1025, 3072, 1024), (77, 8, 64)])
-def test_gemm_bias(cuda, M, N, K):
+def test_gemm_bias(cuda, tile, M, N, K):
     from mj_video_amd import ops
     a, w, b = rnd(M, K, seed=1), rnd(N, K, std=0.05, seed=2), rnd(N, std=0.1, seed=3)
     out = torch.empty(M, N, dtype=BF, device=cuda)
@@ -48,11 +57,12 @@ def test_gemm_bias(cuda, M, N, K):
     assert_close_bf16(out2, (a.float() @ w.float().t()).to(BF), 1, frac_exact=0.98, atol=1e-6, what="gemm_nobias")
 
 
-def test_gemm_exact_integers(cuda):
+@pytest.mark.parametrize("M,N,K", [(200, 136, 192), (513, 520, 64), (700, 256, 128), (256, 1024, 320), (2200, 768, 2048)])
+def test_gemm_exact_integers(cuda, tile, M, N, K):
     """small-integer operands: every product and partial sum is exact in fp32, so the result must be bit-exact
-    (catches any fragment-layout / swizzle / transposition mistake; asymmetric A and W)"""
+    (catches any fragment-layout / swizzle / transposition / pipeline-race mistake; asymmetric A and W;
+    K covers 1, 2, 3, 5 and 32 K-tiles of the software pipeline, M and N ragged against both tile sizes)"""
     from mj_video_amd import ops
-    M, N, K = 200, 136, 192
     g = torch.Generator().manual_seed(5)
     a = torch.randint(-4, 5, (M, K), generator=g).float().to(BF)
     w = torch.randint(-3, 4, (N, K), generator=g).float().to(BF)
@@ -62,7 +72,7 @@ def test_gemm_exact_integers(cuda):
     assert torch.equal(out.cpu(), ref)
 
 
-def test_gemm_gelu_relu(cuda):
+def test_gemm_gelu_relu(cuda, tile):
     from mj_video_amd import ops
     M, N, K = 257, 512, 128
     a, w, b = rnd(M, K, seed=1), rnd(N, K, std=0.1, seed=2), rnd(N, std=0.1, seed=3)
@@ -75,7 +85,7 @@ def test_gemm_gelu_relu(cuda):
     assert_close_bf16(out, F.relu(lin), 1, frac_exact=0.98, atol=1e-6, what="gemm_relu")
 
 
-def test_gemm_scale_res_and_rowmaps(cuda):
+def test_gemm_scale_res_and_rowmaps(cuda, tile):
     from mj_video_amd import ops
     M, N, K = 320, 256, 128
     a, w, b = rnd(M, K, seed=1), rnd(N, K, std=0.1, seed=2), rnd(N, std=0.1, seed=3)
@@ -107,9 +117,9 @@ def test_gemm_scale_res_and_rowmaps(cuda):
     assert_close_bf16(out.cpu()[perm.long()], lin, 1, frac_exact=0.98, atol=1e-6, what="gemm_out_rows")
 
 
-def test_gemm_silu_mul(cuda):
+def test_gemm_silu_mul(cuda, tile):
     from mj_video_amd import ops
-    M, FF, K = 130, 256, 128
+    M, FF, K = 530, 256, 128
     a, w1, w3 = rnd(M, K, seed=1), rnd(FF, K, std=0.1, seed=2), rnd(FF, K, std=0.1, seed=3)
     w13 = torch.stack([w1.view(FF // 16, 16, K), w3.view(FF // 16, 16, K)], dim=1).reshape(2 * FF, K).contiguous()
     out = torch.empty(M, FF, dtype=BF, device=cuda)
@@ -290,3 +300,23 @@ def test_attention_exact_selection(cuda):
     ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), out, cu.to(cuda), L, H, H, D, True, 1.0 / math.sqrt(D), 1)
     exp = v[target]
     assert torch.equal(out.cpu()[:, :D], exp) and torch.equal(out.cpu()[:, D:], exp)
+
+
+def test_gemm_pipeline_race_screen(cuda):
+    """the 256^2 kernel keeps LDS-DMA in flight across barriers: repeat an exact-integer problem many times on a
+    busy chip (many tiles, deep K) and require every run bit-identical to the exact result"""
+    from mj_video_amd import ops
+    ops.gemm_set_tile(256)
+    try:
+        M, N, K = 4096 + 37, 2048, 1024
+        g = torch.Generator().manual_seed(11)
+        a = torch.randint(-3, 4, (M, K), generator=g).float().to(BF).to(cuda)
+        w = torch.randint(-3, 4, (N, K), generator=g).float().to(BF).to(cuda)
+        ref = (a.float() @ w.float().t()).to(BF)
+        out = torch.empty(M, N, dtype=BF, device=cuda)
+        for it in range(20):
+            out.zero_()
+            ops.gemm(a, w, out, ops.EPI_BIAS)
+            assert torch.equal(out, ref), f"iteration {it}: {(out != ref).sum().item()} wrong elements"
+    finally:
+        ops.gemm_set_tile(0)
