@@ -22,8 +22,28 @@
 //
 // Epilogues reproduce the reference's bf16 op boundaries (one rounding per torch op).
 #include "mjv_common.h"
+#include "gelu_table.h"
 
 namespace {
+
+// exact-erf GELU on bf16 as a finite function (tools/gen_gelu_table.py): bit-identical to torch's CPU bf16 GELU
+__device__ const u16 g_gelu_table[MJV_GELU_TABLE_LEN] = MJV_GELU_TABLE_INIT;
+
+// x given as an fp32 value that is exactly representable in bf16; tab = table in LDS or global memory.
+// Branch-free on purpose (selects only): a divergent version costs ~3x more than the table read it guards.
+MJV_DEV float gelu_lut(float xf, const u16* tab) {
+  const unsigned u = __float_as_uint(xf);
+  const unsigned mag = (u >> 16) & 0x7fffu;
+  const unsigned rel = mag - MJV_GELU_LO;                       // wraps to a huge value below the table
+  const unsigned sgn = (unsigned)((int)u >> 31);                // all ones for x < 0
+  const bool in_tab = rel < (unsigned)MJV_GELU_R;
+  const unsigned idx = in_tab ? rel + (sgn & MJV_GELU_R) : 0u;
+  const unsigned t = tab[idx];
+  const unsigned big = sgn ? 0x80000000u : u;                   // beyond the table: x for x > 0, -0 for x < 0
+  const unsigned small = __float_as_uint(0.5f * xf);            // below the table: x / 2
+  const unsigned other = mag < MJV_GELU_LO ? small : big;
+  return __uint_as_float(in_tab ? (t << 16) : other);
+}
 
 struct GemmArgs {
   const u16* A; long lda;
@@ -39,28 +59,6 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-// erf with |error| < 1.2e-7 (Abramowitz-Stegun 7.1.26 refined is not enough; use the W. J. Cody-style
-// rational split cheap enough for an epilogue): for the bf16 output of GELU 1e-6 absolute is far below half an ulp.
-MJV_DEV float erf_fast(float x) {
-  // erf(x) = sign(x) * (1 - t * exp(-x^2 + P(t))),  t = 1 / (1 + 0.5 |x|)   (Numerical Recipes erfc Chebyshev fit,
-  // fractional error < 1.2e-7 everywhere)
-  const float z = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.5f * z);
-  float p = 0.17087277f;
-  p = fmaf(p, t, -0.82215223f);
-  p = fmaf(p, t, 1.48851587f);
-  p = fmaf(p, t, -1.13520398f);
-  p = fmaf(p, t, 0.27886807f);
-  p = fmaf(p, t, -0.18628806f);
-  p = fmaf(p, t, 0.09678418f);
-  p = fmaf(p, t, 0.37409196f);
-  p = fmaf(p, t, 1.00002368f);
-  p = fmaf(p, t, -1.26551223f);
-  const float r = t * __expf(fmaf(-z, z, p));
-  const float e = 1.0f - r;
-  return x >= 0.f ? e : -e;
-}
-MJV_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 MJV_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 MJV_DEV long out_row_of(const GemmArgs& p, int m) {
@@ -85,7 +83,7 @@ MJV_DEV void store_frag(const GemmArgs& p, const f32x4& acc, int m, long orow, i
   }
   if constexpr (EPI == MJV_EPI_BIAS_GELU) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(rbf(v[r]));
+    for (int r = 0; r < 4; ++r) v[r] = gelu_lut(rbf(v[r]), g_gelu_table);
   } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -232,7 +230,12 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
 namespace t256 {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB: 128 rows x 64 k
-constexpr int LDS_BYTES = 8 * HALF_BYTES;  // 2 K-tiles x {W0, W1, A0, A1}
+constexpr int PIPE_BYTES = 8 * HALF_BYTES;  // 2 K-tiles x {W0, W1, A0, A1}
+constexpr int EPI_PITCH = 256 * 2 + 16;     // bf16 output tile staged for coalesced stores: 528-B rows (conflict-free)
+constexpr int EPI_TILE_BYTES = 256 * EPI_PITCH;
+constexpr int GELU_BYTES = MJV_GELU_TABLE_LEN * 2;
+constexpr int LDS_BYTES = EPI_TILE_BYTES + GELU_BYTES;  // 140704 B >= PIPE_BYTES: one workgroup per CU either way
+static_assert(LDS_BYTES >= PIPE_BYTES && LDS_BYTES <= 160 * 1024 && EPI_TILE_BYTES % 16 == 0, "LDS budget");
 
 // stage half-tile number n (order per K-tile: W rows 0-127, W rows 128-255, A rows 0-127, A rows 128-255)
 MJV_DEV void stage_half(const GemmArgs& p, int n, int nk, int m0, int n0, char* smem, int wave, int lane) {
@@ -357,26 +360,90 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef MJV_LOAD_W
 #undef MJV_MFMA
 
-  // ---- epilogue: acc[i][j] = rows n (4 per lane) x column m
+  // ---- epilogue, two passes through LDS (the pipeline buffers are dead: every DMA was retired by the last
+  // vmcnt(0) and the last ds_read is 5 barriers back):
+  //  pass A (fragment layout: lane = output row m, 4 consecutive columns n): + bias, first bf16 rounding, then the
+  //         per-element activation (GELU table / ReLU / SiLU*up) -> bf16 tile in LDS;
+  //  pass B (row layout: 32 lanes x 16 B = one 512-B output row): LayerScale / residual, coalesced 16-B global
+  //         loads and stores (an 8-B-per-lane fragment store touches 16 rows x 32 B per instruction and ran the
+  //         K = 1024 GEMMs at half speed).
+  char* etile = smem;
+  u16* gtab = (u16*)(smem + EPI_TILE_BYTES);
+  if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+    for (int c = tid; c < MJV_GELU_TABLE_LEN / 8; c += 512) ((u32x4*)gtab)[c] = ((const u32x4*)g_gelu_table)[c];
+    __syncthreads();
+  }
+  constexpr int OUT_COLS = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wr * 128 + i * 16 + l15;
-    if (m >= p.M) continue;
-    const long orow = out_row_of(p, m);
-    if constexpr (EPI == MJV_EPI_SILU_MUL) {
+  for (int j = 0; j < 4; ++j) {
+    const int nl = wc * 64 + j * 16 + l4 * 4;   // column inside the 256-wide weight tile
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI != MJV_EPI_SILU_MUL && p.bias && n0 + nl < p.N) {
+      const u32x2 bb = *(const u32x2*)(p.bias + n0 + nl);
+      b4[0] = __uint_as_float(bb[0] << 16);
+      b4[1] = __uint_as_float(bb[0] & 0xffff0000u);
+      b4[2] = __uint_as_float(bb[1] << 16);
+      b4[3] = __uint_as_float(bb[1] & 0xffff0000u);
+    }
+    if (EPI == MJV_EPI_SILU_MUL && (j & 1)) continue;
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        const int n = n0 + wc * 64 + j * 16 + l4 * 4;
-        if (n >= p.N) continue;
-        store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wc * 64) / 2 + (j / 2) * 16 + l4 * 4);
+    for (int i = 0; i < 8; ++i) {
+      const int ml = wr * 128 + i * 16 + l15;
+      float v[4];
+      int col;
+      if constexpr (EPI == MJV_EPI_SILU_MUL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(silu(rbf(acc[i][j][r]))) * rbf(acc[i][j + 1][r]);
+        col = wc * 32 + (j >> 1) * 16 + l4 * 4;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + b4[r];
+        if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_lut(rbf(v[r]), gtab);
+        } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        col = nl;
       }
-    } else {
+      const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *(u32x2*)(etile + ml * EPI_PITCH + col * 2) = o;
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int LANES_PER_ROW = OUT_COLS / 8;          // 16-B chunks per output row
+    constexpr int ROWS_PER_PASS = 512 / LANES_PER_ROW;
+    const int c8 = (tid % LANES_PER_ROW) * 8;
+    const int nout0 = (EPI == MJV_EPI_SILU_MUL) ? n0 / 2 : n0;
+    const int nlim = (EPI == MJV_EPI_SILU_MUL) ? p.N / 2 : p.N;
+    const int n = nout0 + c8;
+    float sc[8];
+    if constexpr (EPI == MJV_EPI_SCALE_RES) {
+      if (p.scale && n < nlim) unpack8(*(const u32x4*)(p.scale + n), sc);
+    }
+#pragma unroll 4
+    for (int r0 = 0; r0 < 256; r0 += ROWS_PER_PASS) {
+      const int ml = r0 + tid / LANES_PER_ROW;
+      const int m = m0 + ml;
+      if (m >= p.M || n >= nlim) continue;
+      u32x4 val = *(const u32x4*)(etile + ml * EPI_PITCH + c8 * 2);
+      const long orow = out_row_of(p, m);
+      if constexpr (EPI == MJV_EPI_SCALE_RES) {
+        float v[8], rs[8];
+        unpack8(val, v);
+        if (p.scale) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + l4 * 4;
-        if (n >= p.N) continue;
-        store_frag<EPI>(p, acc[i][j], m, orow, n);
+          for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * sc[e]);
+        }
+        const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;
+        unpack8(*(const u32x4*)(p.res + rrow * p.ldr + n), rs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rs[e];
+        val = pack8(v);
       }
+      *(u32x4*)(p.C + orow * p.ldc + n) = val;
     }
   }
 }

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""GEMM micro-benchmark on the GPU box: TFLOP/s per shape / epilogue / tile kernel (HIP events, random data)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import mj_video_amd
+from mj_video_amd import ops
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+
+
+def bench(M, N, K, epi, tile, iters=20):
+    a = torch.randn(M, K, device=dev, dtype=torch.float32).to(BF)
+    w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.05).to(BF)
+    nout = N // 2 if epi == ops.EPI_SILU_MUL else N
+    out = torch.empty(M, nout, device=dev, dtype=BF)
+    bias = torch.randn(N, device=dev).to(BF) if epi not in (ops.EPI_SILU_MUL,) else None
+    res = torch.randn(M, nout, device=dev).to(BF) if epi == ops.EPI_SCALE_RES else None
+    scale = torch.randn(N, device=dev).to(BF) if epi == ops.EPI_SCALE_RES else None
+    ops.gemm_set_tile(tile)
+    for _ in range(3):
+        ops.gemm(a, w, out, epi, bias=bias, scale=scale, res=res)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.gemm(a, w, out, epi, bias=bias, scale=scale, res=res)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    ops.gemm_set_tile(0)
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+
+shapes = [("square8k", 8192, 8192, 8192, ops.EPI_BIAS), ("square4k", 4096, 4096, 4096, ops.EPI_BIAS),
+          ("vit_qkv", 65600, 3072, 1024, ops.EPI_BIAS), ("vit_proj", 65600, 1024, 1024, ops.EPI_SCALE_RES),
+          ("vit_fc1", 65600, 4096, 1024, ops.EPI_BIAS_GELU), ("vit_fc1_nogelu", 65600, 4096, 1024, ops.EPI_BIAS),
+          ("vit_fc2", 65600, 1024, 4096, ops.EPI_SCALE_RES),
+          ("llm_wqkv", 17488, 4096, 2048, ops.EPI_BIAS), ("llm_wo", 17488, 2048, 2048, ops.EPI_SCALE_RES),
+          ("llm_w13", 17488, 16384, 2048, ops.EPI_SILU_MUL), ("llm_w2", 17488, 2048, 8192, ops.EPI_SCALE_RES),
+          ("llm_w2_16384", 16384, 2048, 8192, ops.EPI_SCALE_RES)]
+tiles = [int(t) for t in sys.argv[1:]] or [256]
+for name, M, N, K, epi in shapes:
+    line = f"{name:16s} M={M:6d} N={N:6d} K={K:5d}"
+    for t in tiles:
+        ms, tf = bench(M, N, K, epi, t)
+        line += f" | tile{t}: {ms:8.3f} ms {tf:7.1f} TF/s"
+    print(line, flush=True)
