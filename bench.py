@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=4, help="pairs per GPU per step (BASELINE.json configs[1]: 4)")
     ap.add_argument("--image-size", type=int, default=448)
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=2, help="sample groups scored concurrently on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -110,6 +111,7 @@ def main():
     model.config.pad_token_id = synth.PAD_ID
     model.model.img_context_token_id = synth.IMG_CONTEXT_ID
     model.eval()
+    model.n_streams = args.streams
 
     n_videos = 2 * args.pairs
     per_tile = num_image_tokens_per_tile(cfg)
@@ -170,6 +172,7 @@ def main():
             "config": {"workload": f"MJ-VIDEO-2B, batch={args.pairs} pairs per GPU, {F} frames @{S}^2 max_num=1, "
                                    f"N={seq_len} tokens/video, random-init weights, inputs resident in HBM",
                        "pairs_per_gpu_per_step": args.pairs, "global_pairs_per_step": args.pairs * world,
+                       "hip_streams_per_gpu": args.streams,
                        "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
             "frac_of_mfma_roofline": round(value * ALGO_TFLOP_PER_PAIR / (MFMA_BF16_PEAK_TFLOPS * world), 4)
             if (S, F) == (448, 8) else None,

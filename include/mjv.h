@@ -140,11 +140,11 @@ int mjv_cls_rows_bf16(mjv_bf16* x, int64_t ldx, const mjv_bf16* cls, const mjv_b
 int mjv_embed_gather_bf16(const int32_t* ids, const mjv_bf16* table, int64_t ldt, mjv_bf16* x, int64_t ldx,
                           int32_t rows, int32_t dim, int32_t skip_id, int32_t vocab, void* stream);
 
-/* Reward / gating heads (moe_reward.py:226-285).  hn = post-final-norm rows: [0,B) reward rows h_r,
- * [B,2B) gating rows h_g.  ga/gc = outputs of the last hidden layer (post-ReLU) of the aspect / criteria
+/* Reward / gating heads (moe_reward.py:226-285).  hr / hg = post-final-norm reward rows h_r and gating rows h_g
+ * ([B][hidden] each, row stride ldh).  ga/gc = outputs of the last hidden layer (post-ReLU) of the aspect / criteria
  * gating MLPs.  Outputs follow CustomOutput (moe_reward.py:287-297). */
 typedef struct mjv_heads_desc {
-  const mjv_bf16* hn; int64_t ldh; int32_t hidden;
+  const mjv_bf16* hr; const mjv_bf16* hg; int64_t ldh; int32_t hidden;
   const mjv_bf16* ga; const mjv_bf16* gc; int64_t ldg; int32_t gate_hidden;
   const mjv_bf16* w_reg;      /* [n_obj][hidden]  regression_layer.weight */
   const mjv_bf16* w_transform;/* [n_obj][n_obj]   reward_transform_matrix */

@@ -41,7 +41,7 @@ class AttnDesc(C.Structure):
 
 
 class HeadsDesc(C.Structure):
-    _fields_ = [("hn", C.c_void_p), ("ldh", C.c_int64), ("hidden", C.c_int32),
+    _fields_ = [("hr", C.c_void_p), ("hg", C.c_void_p), ("ldh", C.c_int64), ("hidden", C.c_int32),
                 ("ga", C.c_void_p), ("gc", C.c_void_p), ("ldg", C.c_int64), ("gate_hidden", C.c_int32),
                 ("w_reg", C.c_void_p), ("w_transform", C.c_void_p), ("wa", C.c_void_p), ("ba", C.c_void_p),
                 ("wc", C.c_void_p), ("bc", C.c_void_p), ("ls_a", C.c_void_p), ("ls_c", C.c_void_p),

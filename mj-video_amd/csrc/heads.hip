@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void reward_heads_kernel(HeadsArgs args) {
       s_ascore[MAX_ASP];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u16* h_r = p.hn + (long)b * p.ldh;
+  const u16* h_r = p.hr + (long)b * p.ldh;
   const u16* g_a = p.ga + (long)b * p.ldg;
   const u16* g_c = p.gc + (long)b * p.ldg;
 
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void reward_heads_kernel(HeadsArgs args) {
 }  // namespace
 
 extern "C" int mjv_reward_heads_bf16(const mjv_heads_desc* d, void* stream) {
-  MJV_REQUIRE(d && d->hn && d->ga && d->gc && d->w_reg && d->w_transform && d->wa && d->ba && d->wc && d->bc && d->ls_a &&
+  MJV_REQUIRE(d && d->hr && d->hg && d->ga && d->gc && d->w_reg && d->w_transform && d->wa && d->ba && d->wc && d->bc && d->ls_a &&
                   d->ls_c && d->group_offsets && d->group_index, "heads: null input pointer");
   MJV_REQUIRE(d->rewards && d->criteria_gating && d->aspect_gating && d->aspect_weights && d->weighted_last &&
                   d->aspect_scores && d->score, "heads: null output pointer");

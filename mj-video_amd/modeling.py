@@ -318,6 +318,9 @@ class InternVLChatRewardModeling(nn.Module):
         self._ws: Dict[str, torch.Tensor] = {}
         self._rope: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.last_packed34: Optional[torch.Tensor] = None
+        self._ws_tag = "g0"
+        self._streams: List[torch.cuda.Stream] = []
+        self.n_streams = 2  # sample groups scored concurrently on separate HIP streams (1 = single stream)
         self.debug_probes: Optional[Dict[str, torch.Tensor]] = None  # tests set {} to capture per-layer states
 
     # -- construction helpers -------------------------------------------------------------------
@@ -419,6 +422,7 @@ class InternVLChatRewardModeling(nn.Module):
         return tabs
 
     def _buf(self, name: str, rows: int, cols: int, device, dtype=BF16) -> torch.Tensor:
+        name = f"{self._ws_tag}:{name}"
         t = self._ws.get(name)
         need = rows * cols
         if t is None or t.numel() < need or t.device != device or t.dtype != dtype:
@@ -508,7 +512,7 @@ class InternVLChatRewardModeling(nn.Module):
         h = self._buf("vit_h", rows, dim, dev)
         qkv = self._buf("vit_qkv", rows, 3 * dim, dev)
         f = self._buf("vit_ff", rows, ff, dev)
-        key = ("vit_cu", tiles, T)
+        key = (self._ws_tag, "vit_cu", tiles, T)
         cu = self._ws.get(key)
         if cu is None or cu.device != dev:
             cu = torch.arange(0, (tiles + 1) * T, T, dtype=torch.int32, device=dev)
@@ -566,6 +570,84 @@ class InternVLChatRewardModeling(nn.Module):
         return x
 
     # -- forward ---------------------------------------------------------------------------------
+    def _forward_group(self, d, tag: str, pixel_values, input_ids, attention_mask, outs, lo: int, probes_ok: bool):
+        """Scores samples [lo, lo+B) of the batch on the CURRENT stream with its own workspace ``tag``."""
+        dev = pixel_values.device
+        self._ws_tag = tag
+        info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])
+        B, total = info["B"], info["total"]
+        lc = self.config.llm_config
+        hdim = lc.hidden_size
+
+        def up(a):
+            return torch.from_numpy(a).to(dev, non_blocking=True)
+
+        ids, positions, cu = up(info["ids"]), up(info["positions"]), up(info["cu"])
+        img_rows, sel_rows = up(info["img_rows"]), up(info["sel_rows"])
+        hidden = self._buf("llm_x", total, hdim, dev)
+        ops.embed_gather(ids, self.model.language_model.model.tok_embeddings.weight, hidden, self.model.img_context_token_id)
+        self._vision_tower(d, pixel_values, hidden, img_rows)
+        if self.debug_probes is not None and probes_ok:
+            self.debug_probes["llm_embed"] = hidden.clone()
+        self._language_tower(d, hidden, cu, positions, info["max_len"])
+
+        # final RMSNorm only on the 2 rows per sample the heads read (hidden_states[-1] is post-norm, moe_reward.py:211)
+        h_r, h_g = outs["hidden_state"][lo:lo + B], outs["prompt_embedding"][lo:lo + B]
+        norm_w = self.model.language_model.model.norm.weight
+        ops.rmsnorm(hidden, norm_w, h_r, lc.rms_norm_eps, row_index=sel_rows[:B])
+        ops.rmsnorm(hidden, norm_w, h_g, lc.rms_norm_eps, row_index=sel_rows[B:])
+        gh = self.aspect_gating.layers[0].out_features
+
+        def gating_hidden(net: GatingNetwork, name: str) -> torch.Tensor:
+            cur = h_g
+            for j, layer in enumerate(net.layers[:-1]):
+                out = self._buf(f"gate_{name}{j & 1}", B, layer.out_features, dev)
+                ops.gemm(cur, layer.weight, out, EPI_BIAS_RELU, bias=layer.bias)
+                cur = out
+            return cur
+
+        ga = gating_hidden(self.aspect_gating, "a")
+        gc = gating_hidden(self.criteria_gating, "c")
+        nobj, nasp = self.num_objectives, self.num_aspects
+        hd = HeadsDesc()
+        hd.hr, hd.hg, hd.ldh, hd.hidden = h_r.data_ptr(), h_g.data_ptr(), h_r.stride(0), hdim
+        hd.ga, hd.gc, hd.ldg, hd.gate_hidden = ga.data_ptr(), gc.data_ptr(), ga.stride(0), gh
+        hd.w_reg = self.regression_layer.weight.data_ptr()
+        hd.w_transform = self.reward_transform_matrix.data_ptr()
+        la, lcg = self.aspect_gating.layers[-1], self.criteria_gating.layers[-1]
+        hd.wa, hd.ba, hd.wc, hd.bc = la.weight.data_ptr(), la.bias.data_ptr(), lcg.weight.data_ptr(), lcg.bias.data_ptr()
+        hd.ls_a, hd.ls_c = self.aspect_gating.logit_scale.data_ptr(), self.criteria_gating.logit_scale.data_ptr()
+        hd.temperature = float(self.criteria_gating.temperature)
+        hd.batch, hd.n_obj, hd.n_asp = B, nobj, nasp
+        hd.group_offsets, hd.group_index = d["group_offsets"].data_ptr(), d["group_index"].data_ptr()
+        hd.rewards = outs["rewards"][lo:].data_ptr()
+        hd.criteria_gating = outs["criteria_gating_output"][lo:].data_ptr()
+        hd.aspect_gating = outs["aspect_gating_output"][lo:].data_ptr()
+        hd.aspect_weights = outs["aspect_weights"][lo:].data_ptr()
+        hd.weighted_last = outs["weighted_scores"][lo:].data_ptr()
+        hd.aspect_scores = outs["aspect_scores"][lo:].data_ptr()
+        hd.score = outs["score"][lo:].data_ptr()
+        hd.packed34 = outs["packed34"][lo:].data_ptr()
+        ops.reward_heads(hd)
+
+    def _split_batch(self, input_ids: torch.Tensor, n_tiles: int, groups: int):
+        """[(sample_lo, sample_hi, tile_lo, tile_hi)] - contiguous sample groups with their pixel tiles."""
+        B = input_ids.shape[0]
+        groups = max(1, min(groups, B))
+        if groups == 1:
+            return [(0, B, 0, n_tiles)]
+        ctx = self.model.img_context_token_id
+        per = self.model.num_image_token
+        counts = (input_ids.detach().to("cpu") == ctx).sum(dim=1).tolist()
+        tiles = [c // per for c in counts]
+        out, s0, t0 = [], 0, 0
+        for g in range(groups):
+            s1 = (B * (g + 1)) // groups
+            t1 = t0 + sum(tiles[s0:s1])
+            out.append((s0, s1, t0, t1))
+            s0, t0 = s1, t1
+        return out
+
     @torch.no_grad()
     def forward(self, pixel_values: torch.Tensor, input_ids: torch.Tensor = None,
                 attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
@@ -584,66 +666,51 @@ class InternVLChatRewardModeling(nn.Module):
         if pixel_values.dtype != BF16:
             raise TypeError(f"pixel_values must be bfloat16 like the model (got {pixel_values.dtype}); "
                             "callers cast with .to(torch.bfloat16) (eval_genai_mjvideo.py:131)")
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [batch, seq], got {tuple(input_ids.shape)}")
+        if self.model.img_context_token_id is None:
+            raise ValueError("model.model.img_context_token_id is not set (eval_genai_mjvideo.py:115)")
         pixel_values = pixel_values.to(dev).contiguous()
-        info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])
-        B, total = info["B"], info["total"]
-        lc = self.config.llm_config
-        hdim = lc.hidden_size
-
-        def up(a):
-            return torch.from_numpy(a).to(dev, non_blocking=True)
-
-        ids, positions, cu = up(info["ids"]), up(info["positions"]), up(info["cu"])
-        img_rows, sel_rows = up(info["img_rows"]), up(info["sel_rows"])
-
-        hidden = self._buf("llm_x", total, hdim, dev)
-        ops.embed_gather(ids, self.model.language_model.model.tok_embeddings.weight, hidden, self.model.img_context_token_id)
-        self._vision_tower(d, pixel_values, hidden, img_rows)
-        if self.debug_probes is not None:
-            self.debug_probes["llm_embed"] = hidden.clone()
-        self._language_tower(d, hidden, cu, positions, info["max_len"])
-
-        # final RMSNorm only on the 2 rows per sample the heads read (hidden_states[-1] is post-norm, moe_reward.py:211)
-        sel = torch.empty(2 * B, hdim, dtype=BF16, device=dev)
-        ops.rmsnorm(hidden, self.model.language_model.model.norm.weight, sel, lc.rms_norm_eps, row_index=sel_rows)
-        h_g = sel[B:]
-        gh = self.aspect_gating.layers[0].out_features
-
-        def gating_hidden(net: GatingNetwork, tag: str) -> torch.Tensor:
-            cur = h_g
-            for j, layer in enumerate(net.layers[:-1]):
-                out = self._buf(f"gate_{tag}{j & 1}", B, layer.out_features, dev)
-                ops.gemm(cur, layer.weight, out, EPI_BIAS_RELU, bias=layer.bias)
-                cur = out
-            return cur
-
-        ga = gating_hidden(self.aspect_gating, "a")
-        gc = gating_hidden(self.criteria_gating, "c")
+        B = input_ids.shape[0]
+        if self.config.pad_token_id is None and B != 1:   # moe_reward.py:218-219
+            raise ValueError("Cannot handle batch sizes > 1 if no padding token is defined.")
+        hdim = self.config.llm_config.hidden_size
         nobj, nasp = self.num_objectives, self.num_aspects
-        rewards = torch.empty(B, nobj, dtype=BF16, device=dev)
-        crit = torch.empty(B, nobj, dtype=BF16, device=dev)
-        asp_gate = torch.empty(B, nasp, dtype=BF16, device=dev)
-        asp_w = torch.empty(B, nobj, dtype=BF16, device=dev)
-        weighted = torch.empty(B, dtype=BF16, device=dev)
-        asp_scores = torch.empty(B, nasp, dtype=torch.float32, device=dev)
-        score = torch.empty(B, dtype=torch.float32, device=dev)
-        packed = torch.empty(B, 1 + nasp + nobj, dtype=torch.float32, device=dev)
-        hd = HeadsDesc()
-        hd.hn, hd.ldh, hd.hidden = sel.data_ptr(), sel.stride(0), hdim
-        hd.ga, hd.gc, hd.ldg, hd.gate_hidden = ga.data_ptr(), gc.data_ptr(), ga.stride(0), gh
-        hd.w_reg = self.regression_layer.weight.data_ptr()
-        hd.w_transform = self.reward_transform_matrix.data_ptr()
-        la, lcg = self.aspect_gating.layers[-1], self.criteria_gating.layers[-1]
-        hd.wa, hd.ba, hd.wc, hd.bc = la.weight.data_ptr(), la.bias.data_ptr(), lcg.weight.data_ptr(), lcg.bias.data_ptr()
-        hd.ls_a, hd.ls_c = self.aspect_gating.logit_scale.data_ptr(), self.criteria_gating.logit_scale.data_ptr()
-        hd.temperature = float(self.criteria_gating.temperature)
-        hd.batch, hd.n_obj, hd.n_asp = B, nobj, nasp
-        hd.group_offsets, hd.group_index = d["group_offsets"].data_ptr(), d["group_index"].data_ptr()
-        hd.rewards, hd.criteria_gating, hd.aspect_gating = rewards.data_ptr(), crit.data_ptr(), asp_gate.data_ptr()
-        hd.aspect_weights, hd.weighted_last = asp_w.data_ptr(), weighted.data_ptr()
-        hd.aspect_scores, hd.score, hd.packed34 = asp_scores.data_ptr(), score.data_ptr(), packed.data_ptr()
-        ops.reward_heads(hd)
-        self.last_packed34 = packed
-        return CustomOutput(rewards=rewards, hidden_state=sel[:B], prompt_embedding=h_g, criteria_gating_output=crit,
-                            aspect_gating_output=asp_gate, aspect_weights=asp_w, weighted_scores=weighted,
-                            aspect_scores=asp_scores, score=score)
+        outs = dict(
+            rewards=torch.empty(B, nobj, dtype=BF16, device=dev),
+            hidden_state=torch.empty(B, hdim, dtype=BF16, device=dev),
+            prompt_embedding=torch.empty(B, hdim, dtype=BF16, device=dev),
+            criteria_gating_output=torch.empty(B, nobj, dtype=BF16, device=dev),
+            aspect_gating_output=torch.empty(B, nasp, dtype=BF16, device=dev),
+            aspect_weights=torch.empty(B, nobj, dtype=BF16, device=dev),
+            weighted_scores=torch.empty(B, dtype=BF16, device=dev),
+            aspect_scores=torch.empty(B, nasp, dtype=torch.float32, device=dev),
+            score=torch.empty(B, dtype=torch.float32, device=dev),
+            packed34=torch.empty(B, 1 + nasp + nobj, dtype=torch.float32, device=dev))
+        n_groups = 1 if self.debug_probes is not None else self.n_streams
+        # shared lazily-built tables must exist before the streams fork
+        self._rope_tables(int(input_ids.shape[1]), dev)
+        if pixel_values.shape[-1] % self.config.vision_config.patch_size == 0:
+            self._pos_table(d, pixel_values.shape[-1] // self.config.vision_config.patch_size, dev)
+        groups = self._split_batch(input_ids, pixel_values.shape[0], n_groups)
+        if len(groups) == 1:
+            self._forward_group(d, "g0", pixel_values, input_ids, attention_mask, outs, 0, True)
+        else:
+            # independent sample groups on separate HIP streams: one group's GEMM tail / attention overlaps the
+            # other's kernels on otherwise idle CUs; per-sample math is unchanged (packing is per sample)
+            main = torch.cuda.current_stream(dev)
+            while len(self._streams) < len(groups):
+                self._streams.append(torch.cuda.Stream(device=dev))
+            fork = torch.cuda.Event()
+            fork.record(main)
+            for gi, (s0, s1, t0, t1) in enumerate(groups):
+                st = self._streams[gi]
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    self._forward_group(d, f"g{gi}", pixel_values[t0:t1], input_ids[s0:s1],
+                                        None if attention_mask is None else attention_mask[s0:s1], outs, s0, False)
+                    done = torch.cuda.Event()
+                    done.record(st)
+                main.wait_event(done)
+        self.last_packed34 = outs.pop("packed34")
+        return CustomOutput(**outs)

