@@ -11,6 +11,7 @@
 // "An accumulator tile as the next MFMA's operand"): O^T keeps the query on the lane, so the online
 // softmax rescale is a per-lane scalar multiply.
 #include "mjv_common.h"
+#include <math.h>
 
 namespace {
 
@@ -39,7 +40,20 @@ struct Cfg {
   static constexpr int LOADS = KB * CHUNKS / 256;       // chunks per thread per tile
 };
 
-template <int D, bool CAUSAL>
+// score-rounding modes (template parameter): the reference rounds the scores to bf16 before the softmax
+//   RM_MUL   s = bf16(acc * scale)                 [(q * scale) @ k^T, generic scale]
+//   RM_POW2  s = bf16(acc) * scale                 [same thing when scale is a power of two: exact, one op less]
+//   RM_DIV   s = bf16(bf16(acc) * scale)           [q @ k^T, then / sqrt(D) on the bf16 tensor]
+enum { RM_MUL = 0, RM_DIV = 1, RM_POW2 = 2 };
+
+template <int RM>
+MJV_DEV float round_score(float a, float scale) {
+  if constexpr (RM == RM_MUL) return rbf(a * scale);
+  if constexpr (RM == RM_DIV) return rbf(rbf(a) * scale);
+  return rbf(a);  // RM_POW2: the scale is folded into the exp2 argument
+}
+
+template <int D, bool CAUSAL, int RM>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[C::K_BYTES + C::V_BYTES];
@@ -71,17 +85,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
   for (int i = 0; i < D / 32; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;   // running max in units of the ROUNDED score (RM_POW2: before the scale)
 
   const int kv_end = CAUSAL ? min(len, (qb + 1) * QB) : len;
   const int n_tiles = (kv_end + KB - 1) / KB;
   const u16* Kg = p.K + (long)kvh * p.khs;
   const u16* Vg = p.V + (long)kvh * p.vhs;
   constexpr float LOG2E = 1.4426950408889634f;
+  const float c_exp = (RM == RM_POW2) ? p.scale * LOG2E : LOG2E;   // p = exp2(s * c_exp - m * c_exp)
 
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    // ---- stage K/V tile (global -> registers -> LDS)
-    u32x4 kreg[C::LOADS], vreg[C::LOADS];
+  // register staging of the NEXT tile (issued before the current tile's math, written to LDS after it)
+  u32x4 kreg[C::LOADS], vreg[C::LOADS];
+  auto load_tile = [&](int kt) {
 #pragma unroll
     for (int c = 0; c < C::LOADS; ++c) {
       const int idx = tid + c * 256;
@@ -91,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
       kreg[c] = *(const u32x4*)(Kg + (long)(s0 + kr) * p.ldk + ch * 8);
       vreg[c] = *(const u32x4*)(Vg + (long)(s0 + kr) * p.ldv + ch * 8);
     }
-    __syncthreads();  // previous tile fully consumed
+  };
+  auto store_tile = [&]() {
 #pragma unroll
     for (int c = 0; c < C::LOADS; ++c) {
       const int idx = tid + c * 256;
@@ -99,7 +115,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
       *(u32x4*)(Ks + row * C::KP + ch * 16) = kreg[c];
       *(u32x4*)(Vs + row * C::VP + ch * 16) = vreg[c];
     }
+  };
+
+  load_tile(0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+    store_tile();
     __syncthreads();
+    if (kt + 1 < n_tiles) load_tile(kt + 1);  // in flight during this tile's MFMA / softmax work
 
     const int k0 = kt * KB;
     if (CAUSAL && k0 > q0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
@@ -118,26 +141,35 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
       }
     }
 
-    // ---- scores with the reference's rounding, masking, online softmax
+    // ---- masks only where a tile straddles the sequence end or the causal diagonal (wave-uniform test)
     const bool need_mask = (k0 + KB > len) || (CAUSAL && (k0 + KB - 1 > q0));
-    float mx = -INFINITY;
+    if (need_mask) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= len || (CAUSAL && key > qi)) sacc[t2][r] = -INFINITY;
+        }
+    }
+    // ---- online softmax.  bf16 rounding is monotone, so the row max is taken on the raw accumulators and rounded once.
+    float mx = sacc[0][0];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = sacc[t2][r];
-        s = p.round_mode ? rbf(rbf(s) * p.scale) : rbf(s * p.scale);
-        if (need_mask) {
-          const int key = k0 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= len || (CAUSAL && key > qi)) s = -INFINITY;
-        }
-        sacc[t2][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[t2][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * LOG2E);
-    const float mb = m_new * LOG2E;
+    const float m_new = fmaxf(m_run, round_score<RM>(mx, p.scale));
+    if (__any(m_new > m_run)) {            // exact: rescale only when some query's running max moved
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mb = m_run * c_exp;
     float psum = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
@@ -145,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
       float pv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pv[r] = exp2f(sacc[t2][r] * LOG2E - mb);
+        pv[r] = __builtin_amdgcn_exp2f(fmaf(round_score<RM>(sacc[t2][r], p.scale), c_exp, -mb));
         psum += pv[r];
       }
 #pragma unroll
@@ -155,12 +187,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
       }
     }
     psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads.
     // element j of the fragment <-> key 32*t2 + 16*s2 + 8*(j>>2) + 4*hi + (j&3)
@@ -204,7 +231,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
 template <int D, bool CAUSAL>
 int launch(const AttnArgs& a, int n_seqs, int max_seqlen, hipStream_t s) {
   dim3 grid((max_seqlen + QB - 1) / QB, a.n_heads, n_seqs);
-  hipLaunchKernelGGL((attn_kernel<D, CAUSAL>), grid, dim3(256), 0, s, a);
+  int e;
+  const bool pow2 = a.round_mode == 0 && frexpf(a.scale, &e) == 0.5f;
+  if (a.round_mode == 1) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV>), grid, dim3(256), 0, s, a);
+  else if (pow2) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_POW2>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_MUL>), grid, dim3(256), 0, s, a);
   return mjv_check_launch("attention");
 }
 
