@@ -179,20 +179,49 @@ def main():
         }
         if prof:
             res = ops.prof_results()
-            tot = sum(r["ms"] for r in res.values())
-            dom = max(res.items(), key=lambda kv: kv[1]["ms"])
-            name, r = dom
-            tfl = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
-            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                                "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(r["launches"], 1), 4),
-                                "share_of_kernel_time": round(r["ms"] / tot, 4) if tot else None}
-            line["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
-                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None,
-                                   "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None}
-                               for k, v in sorted(res.items(), key=lambda kv: -kv[1]["ms"])}
+
+            def roofline(res, steps):
+                tot = sum(r["ms"] for r in res.values())
+                name, r = max(res.items(), key=lambda kv: kv[1]["ms"])
+                tfl = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+                return {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(r["launches"], 1), 4),
+                        "share_of_kernel_time": round(r["ms"] / tot, 4) if tot else None}
+
+            def table(res, steps):
+                return {k: {"ms_per_step": round(v["ms"] / steps, 3),
+                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None,
+                            "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None}
+                        for k, v in sorted(res.items(), key=lambda kv: -kv[1]["ms"])}
+
+            line["roofline"] = roofline(res, args.steps)
+            line["roofline"]["note"] = ("events on each launch stream inside the timed region; with 2 HIP streams kernels of "
+                                        "the two sample groups overlap, so per-launch durations include time shared with "
+                                        "the other stream's kernel (see roofline_isolated)") if args.streams > 1 else \
+                "events on the launch stream inside the timed region"
+            line["kernels"] = table(res, args.steps)
+            if args.streams > 1:
+                # the same step with ONE stream (no co-running kernels): per-kernel durations comparable with rocprofv3
+                model.n_streams = 1
+                step()
+                fence()
+                ops.prof_reset()
+                ops.prof_enable(True)
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step()
+                fence()
+                iso_ms = 1e3 * (time.perf_counter() - t1) / 2
+                ops.prof_enable(False)
+                iso = ops.prof_results()
+                line["roofline_isolated"] = roofline(iso, 2)
+                line["roofline_isolated"]["ms_per_step_single_stream"] = round(iso_ms, 3)
+                line["kernels_isolated"] = table(iso, 2)
+                model.n_streams = args.streams
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            # oneDNN bf16 GEMMs stop scaling (and oversubscribe NUMA domains) far below a 256-thread host: cap at 32
+            threads = min(os.cpu_count() or 1, 32)
             try:
                 v, dt = cpu_baseline(cfg, S, F, threads)
                 line["cpu_baseline"] = {"value": round(v, 5), "unit": "pairs/s", "cores": threads, "kind": "port",

@@ -57,6 +57,7 @@ struct GemmArgs {
   int out_group, out_pad;
   const int* out_rows;
   int tiles_m, tiles_n;
+  int m_base;  // absolute index of row 0 of A (tail launches): output / residual rows are computed from m_base + m
 };
 
 MJV_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
@@ -118,13 +119,21 @@ MJV_DEV void store_silu(const GemmArgs& p, const f32x4& g, const f32x4& u, long 
 }
 
 MJV_DEV void tile_of_block(const GemmArgs& p, int& tm, int& tn) {
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a contiguous
-  // range of the (m-major, n-minor) tile list: its tiles then share activation panels through its own L2.
+  // XCD-aware tile order.  Blocks b and b+8 share an XCD (round-robin dispatch), so every XCD gets a contiguous range
+  // of a tile list that is itself ordered in groups of GM m-tiles x all n-tiles, n-major inside a group: the ~32
+  // tiles an XCD runs concurrently then form a GM x (32/GM) patch that shares GM activation panels and 32/GM weight
+  // panels through that XCD's 4 MiB L2 (row-major order shares 1 + 32 panels: the whole weight matrix was re-fetched
+  // over the fabric once per m-tile row - rocprofv3 FETCH_SIZE 4.7 GB per w1|w3 launch for 139 MB of operands).
+  constexpr int GM = 8;
   const int nwg = gridDim.x, b = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-  const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
-  tm = tile / p.tiles_n;
-  tn = tile - tm * p.tiles_n;
+  const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+  const int per_group = GM * p.tiles_n;
+  const int grp = t / per_group, in_grp = t - grp * per_group;
+  const int first_m = grp * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  tn = in_grp / gsz;
+  tm = first_m + (in_grp - tn * gsz);
 }
 
 // ============================================================================================ 128 x 128
@@ -204,8 +213,9 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l15;
-    if (m >= p.M) continue;
+    const int mrel = m0 + wm * 64 + i * 16 + l15;
+    if (mrel >= p.M) continue;
+    const int m = p.m_base + mrel;
     const long orow = out_row_of(p, m);
     if constexpr (EPI == MJV_EPI_SILU_MUL) {
 #pragma unroll
@@ -426,8 +436,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll 4
     for (int r0 = 0; r0 < 256; r0 += ROWS_PER_PASS) {
       const int ml = r0 + tid / LANES_PER_ROW;
-      const int m = m0 + ml;
-      if (m >= p.M || n >= nlim) continue;
+      if (m0 + ml >= p.M || n >= nlim) continue;
+      const int m = p.m_base + m0 + ml;
       u32x4 val = *(const u32x4*)(etile + ml * EPI_PITCH + c8 * 2);
       const long orow = out_row_of(p, m);
       if constexpr (EPI == MJV_EPI_SCALE_RES) {
@@ -450,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 }  // namespace t256
 
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
+int g_num_cus = 256;
 
 template <int EPI>
 int launch(GemmArgs a, hipStream_t s, bool big) {
@@ -503,16 +514,53 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.res_mod = d->res_mod; a.res_off = d->res_off; a.out_group = d->out_group; a.out_pad = d->out_pad;
   a.out_rows = d->out_rows;
   a.tiles_m = a.tiles_n = 0;
+  a.m_base = 0;
   const bool big = g_force_tile ? g_force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * d->M * (double)d->N * d->K;
   const double bytes = 2.0 * ((double)d->M * d->K + (double)d->N * d->K + (double)d->M * d->N);
-  switch (d->epilogue) {
-    case MJV_EPI_BIAS: { MjvProfScope ps("gemm_bias", s, flops, bytes); return launch<MJV_EPI_BIAS>(a, s, big); }
-    case MJV_EPI_BIAS_GELU: { MjvProfScope ps("gemm_bias_gelu", s, flops, bytes); return launch<MJV_EPI_BIAS_GELU>(a, s, big); }
-    case MJV_EPI_BIAS_RELU: { MjvProfScope ps("gemm_bias_relu", s, flops, bytes); return launch<MJV_EPI_BIAS_RELU>(a, s, big); }
-    case MJV_EPI_SCALE_RES: { MjvProfScope ps("gemm_scale_res", s, flops, bytes); return launch<MJV_EPI_SCALE_RES>(a, s, big); }
-    case MJV_EPI_SILU_MUL: { MjvProfScope ps("gemm_silu_mul", s, flops, bytes); return launch<MJV_EPI_SILU_MUL>(a, s, big); }
-    default: mjv_set_error("gemm: unknown epilogue %d", d->epilogue); return MJV_E_ARG;
+  // Wave quantisation: with one 256x256 workgroup per CU a launch runs in ceil(tiles / 256) rounds, and a last round
+  // that is mostly empty costs a full tile time (M = 17488, N = 2048: 552 tiles = 2.16 rounds -> 3).  When the last
+  // round is under-filled, the trailing m-tile rows are peeled off and run as 128x128 tiles (2 workgroups per CU,
+  // quarter-size work items) in a second launch on the same stream; rows are independent, so results are unchanged.
+  int m_main = d->M;
+  if (big && !g_force_tile && !d->out_rows) {
+    const int tn = (d->N + 255) / 256, tmx = (d->M + 255) / 256;
+    const int tiles = tn * tmx;
+    const int rem = tiles % g_num_cus;
+    const int rows_main_tiles = (tiles - rem) / tn;  // whole m-tile rows inside the full rounds
+    if (tiles > g_num_cus && rem > 0 && rem * 4 <= g_num_cus * 2 && rows_main_tiles > 0) {
+      m_main = rows_main_tiles * 256;
+      if (m_main >= d->M) m_main = d->M;
+    }
   }
+  auto run = [&](GemmArgs g, bool use_big) -> int {
+    switch (d->epilogue) {
+      case MJV_EPI_BIAS: return launch<MJV_EPI_BIAS>(g, s, use_big);
+      case MJV_EPI_BIAS_GELU: return launch<MJV_EPI_BIAS_GELU>(g, s, use_big);
+      case MJV_EPI_BIAS_RELU: return launch<MJV_EPI_BIAS_RELU>(g, s, use_big);
+      case MJV_EPI_SCALE_RES: return launch<MJV_EPI_SCALE_RES>(g, s, use_big);
+      case MJV_EPI_SILU_MUL: return launch<MJV_EPI_SILU_MUL>(g, s, use_big);
+      default: mjv_set_error("gemm: unknown epilogue %d", d->epilogue); return MJV_E_ARG;
+    }
+  };
+  static const char* const tags[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_relu", "gemm_scale_res", "gemm_silu_mul"};
+  if (d->epilogue < 0 || d->epilogue > 4) {
+    mjv_set_error("gemm: unknown epilogue %d", d->epilogue);
+    return MJV_E_ARG;
+  }
+  MjvProfScope ps(tags[d->epilogue], s, flops, bytes);
+  if (m_main == d->M) return run(a, big);
+  GemmArgs head = a;
+  head.M = m_main;
+  int rc = run(head, true);
+  if (rc) return rc;
+  // tail rows [m_main, M): the epilogue row maps depend on the absolute row index only through
+  // res_mod / out_group, both of which are periodic in m; shifting by a multiple of 256 rows keeps them exact only
+  // if the period divides m_main, so the tail kernel gets the absolute offset folded into its pointers instead.
+  GemmArgs tail = a;
+  tail.M = d->M - m_main;
+  tail.A = a.A + (long)m_main * a.lda;
+  tail.m_base = m_main;
+  return run(tail, false);
 }

@@ -320,3 +320,30 @@ def test_gemm_pipeline_race_screen(cuda):
             assert torch.equal(out, ref), f"iteration {it}: {(out != ref).sum().item()} wrong elements"
     finally:
         ops.gemm_set_tile(0)
+
+
+def test_gemm_tail_peeling_is_invisible(cuda):
+    """(operands in {-1,0,1}, K=256: every intermediate is an integer below 256, exact in bf16 at both rounding points)
+    automatic tile choice peels the under-filled last round into a second (128x128-tile) launch: results must not
+    depend on it, including the periodic row maps of the patch-embedding epilogue"""
+    from mj_video_amd import ops
+    ops.gemm_set_tile(0)
+    M, N, K = 17488, 2048, 256           # 69 x 8 = 552 tiles of 256^2 -> 2 full rounds + 40
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(-1, 2, (M, K), generator=g).float().to(BF).to(cuda)
+    w = torch.randint(-1, 2, (N, K), generator=g).float().to(BF).to(cuda)
+    res = torch.randint(-8, 9, (M, N), generator=g).float().to(BF).to(cuda)
+    x = res.clone()
+    ops.gemm(a, w, x, ops.EPI_SCALE_RES, res=x)
+    ref = (res.float() + (a.float() @ w.float().t())).to(BF)
+    assert torch.equal(x, ref)
+    # pos-emb style row maps whose period (1024 rows in, 1025 out) is not aligned with the peeled tail
+    P, M2 = 1024, 69 * 1024
+    a2 = torch.randint(-1, 2, (M2, K), generator=g).float().to(BF).to(cuda)
+    w2 = torch.randint(-1, 2, (2048, K), generator=g).float().to(BF).to(cuda)
+    table = torch.randint(-8, 9, (P + 1, 2048), generator=g).float().to(BF).to(cuda)
+    out = torch.zeros(M2 + M2 // P, 2048, dtype=BF, device=cuda)
+    ops.gemm(a2, w2, out, ops.EPI_SCALE_RES, res=table, res_mod=P, res_off=1, out_group=P, out_pad=1)
+    ref2 = ((a2.float() @ w2.float().t()).view(-1, P, 2048) + table[1:].float()).to(BF)
+    got = out.view(-1, P + 1, 2048)
+    assert torch.equal(got[:, 1:], ref2) and (got[:, 0] == 0).all()
