@@ -46,6 +46,17 @@ struct Cfg {
 //   RM_DIV   s = bf16(bf16(acc) * scale)           [q @ k^T, then / sqrt(D) on the bf16 tensor]
 enum { RM_MUL = 0, RM_DIV = 1, RM_POW2 = 2 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// two fp32 -> packed bf16 pair in one v_cvt_pk_bf16_f32
+MJV_DEV unsigned pack_pair(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+// round two fp32 values through bf16 (one conversion, two unpack ops)
+MJV_DEV f32x2 round_pair(f32x2 v) {
+  const unsigned u = pack_pair(v);
+  return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+
 template <int RM>
 MJV_DEV float round_score(float a, float scale) {
   if constexpr (RM == RM_MUL) return rbf(a * scale);
@@ -169,23 +180,30 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
       m_run = m_new;
     }
-    const float mb = m_run * c_exp;
-    float psum = 0.f;
+    // exponentials, two keys per step so that conversions and the affine map use the packed forms
+    // (v_cvt_pk_bf16_f32, v_pk_fma_f32, v_pk_add_f32): the softmax is VALU-bound, not MFMA-bound
+    const f32x2 c2 = {c_exp, c_exp};
+    const f32x2 nmb2 = {-m_run * c_exp, -m_run * c_exp};
+    f32x2 psum2 = {0.f, 0.f};
     bf16x8 pf[2][2];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
-      float pv[16];
+      unsigned pw[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(fmaf(round_score<RM>(sacc[t2][r], p.scale), c_exp, -mb));
-        psum += pv[r];
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 a2 = {sacc[t2][r], sacc[t2][r + 1]};
+        f32x2 sr = round_pair(a2);
+        if constexpr (RM == RM_MUL) sr = round_pair(a2 * f32x2{p.scale, p.scale});
+        if constexpr (RM == RM_DIV) sr = round_pair(sr * f32x2{p.scale, p.scale});
+        const f32x2 e2 = sr * c2 + nmb2;
+        const f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+        psum2 += pv;
+        pw[r >> 1] = pack_pair(pv);
       }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        u32x4 w = pack8(pv + 8 * s2);
-        pf[t2][s2] = __builtin_bit_cast(bf16x8, w);
-      }
+      pf[t2][0] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+      pf[t2][1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
     }
+    float psum = psum2[0] + psum2[1];
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
 

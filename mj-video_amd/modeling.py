@@ -539,7 +539,11 @@ class InternVLChatRewardModeling(nn.Module):
             probes["vit_embeds"] = hidden[img_rows.long()].clone().view(tiles, -1, hidden.shape[1])
         return x
 
-    def _language_tower(self, d, x: torch.Tensor, cu: torch.Tensor, positions: torch.Tensor, max_len: int):
+    def _language_tower(self, d, x: torch.Tensor, cu: torch.Tensor, positions: torch.Tensor, max_len: int,
+                        sel_rows: Optional[torch.Tensor] = None):
+        """24 decoder layers in place on the packed rows ``x``.  With ``sel_rows`` (the 2 rows per sample the heads
+        read) the LAST layer runs wo / FFN only on those rows - every other row of its output is never used
+        (moe_reward.py:211,229,243) - and the [len(sel_rows), hidden] result is returned instead of ``x``."""
         dev = x.device
         lc = self.config.llm_config
         lm = self.model.language_model.model
@@ -556,11 +560,25 @@ class InternVLChatRewardModeling(nn.Module):
         act = self._buf("llm_act", n, ff, dev)
         scale = 1.0 / math.sqrt(hd)
         v_view = qkv[:, (G + 1) * hd:]
+        last = len(lm.layers) - 1
         for li, layer in enumerate(lm.layers):
             ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
             ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_BIAS)
             ops.rope_split(qkv, q, k, cos, sin, positions, KV, G)
             ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, 1, v_head_stride=(G + 2) * hd)
+            if li == last and sel_rows is not None and self.debug_probes is None:
+                ns = sel_rows.numel()
+                att_s = self._buf("llm_att_sel", ns, hdim, dev)
+                x_s = self._buf("llm_x_sel", ns, hdim, dev)
+                hn_s = self._buf("llm_hn_sel", ns, hdim, dev)
+                act_s = self._buf("llm_act_sel", ns, ff, dev)
+                ops.embed_gather(sel_rows, hn, att_s, -1)     # row gathers (table = activation rows)
+                ops.embed_gather(sel_rows, x, x_s, -1)
+                ops.gemm(att_s, layer.attention.wo.weight, x_s, EPI_SCALE_RES, res=x_s)
+                ops.rmsnorm(x_s, layer.ffn_norm.weight, hn_s, lc.rms_norm_eps)
+                ops.gemm(hn_s, d["w13"][li], act_s, EPI_SILU_MUL)
+                ops.gemm(act_s, layer.feed_forward.w2.weight, x_s, EPI_SCALE_RES, res=x_s)
+                return x_s
             ops.gemm(hn, layer.attention.wo.weight, x, EPI_SCALE_RES, res=x)
             ops.rmsnorm(x, layer.ffn_norm.weight, hn, lc.rms_norm_eps)
             ops.gemm(hn, d["w13"][li], act, EPI_SILU_MUL)
@@ -589,13 +607,18 @@ class InternVLChatRewardModeling(nn.Module):
         self._vision_tower(d, pixel_values, hidden, img_rows)
         if self.debug_probes is not None and probes_ok:
             self.debug_probes["llm_embed"] = hidden.clone()
-        self._language_tower(d, hidden, cu, positions, info["max_len"])
+        trimmed = self.debug_probes is None
+        last_x = self._language_tower(d, hidden, cu, positions, info["max_len"], sel_rows if trimmed else None)
 
         # final RMSNorm only on the 2 rows per sample the heads read (hidden_states[-1] is post-norm, moe_reward.py:211)
         h_r, h_g = outs["hidden_state"][lo:lo + B], outs["prompt_embedding"][lo:lo + B]
         norm_w = self.model.language_model.model.norm.weight
-        ops.rmsnorm(hidden, norm_w, h_r, lc.rms_norm_eps, row_index=sel_rows[:B])
-        ops.rmsnorm(hidden, norm_w, h_g, lc.rms_norm_eps, row_index=sel_rows[B:])
+        if trimmed:   # last_x holds exactly the selected rows: [0, B) reward rows, [B, 2B) gating rows
+            ops.rmsnorm(last_x[:B], norm_w, h_r, lc.rms_norm_eps)
+            ops.rmsnorm(last_x[B:], norm_w, h_g, lc.rms_norm_eps)
+        else:
+            ops.rmsnorm(hidden, norm_w, h_r, lc.rms_norm_eps, row_index=sel_rows[:B])
+            ops.rmsnorm(hidden, norm_w, h_g, lc.rms_norm_eps, row_index=sel_rows[B:])
         gh = self.aspect_gating.layers[0].out_features
 
         def gating_hidden(net: GatingNetwork, name: str) -> torch.Tensor:

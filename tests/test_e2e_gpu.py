@@ -197,6 +197,30 @@ def test_rank_agreement_c1(cuda):
     assert sep >= 0.999
 
 
+def test_streams_and_last_layer_trimming_are_invisible(cuda):
+    """production path (2 HIP streams, last decoder layer evaluated only on the rows the heads read) vs the plain
+    single-stream full evaluation: every output field bit-identical (per-sample math is unchanged)"""
+    from mj_video_amd import synth
+    cfg = make_cfg("2b", 224)
+    sd = synth.synth_state_dict(cfg, seed=0, lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
+        cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
+    model = build_hip_model(cfg, sd, cuda)
+    vids = [dict(video_idx=i, n_tiles=t, caption_seed=i) for i, t in enumerate([8, 6, 8, 3, 5])]
+    px, ids, mask, _ = case_inputs(cfg, vids, 77, 224)
+    px, ids, mask = px.to(cuda), ids.to(cuda), mask.to(cuda)
+    model.n_streams = 2
+    fast = model.forward(px, ids, mask)
+    model.n_streams = 1
+    one = model.forward(px, ids, mask)
+    model.debug_probes = {}
+    full = model.forward(px, ids, mask)
+    model.debug_probes = None
+    for f in FIELDS:
+        assert torch.equal(getattr(fast, f), getattr(full, f)), f
+        assert torch.equal(getattr(one, f), getattr(full, f)), f
+
+
 def test_error_behaviour(cuda):
     """the reference's ValueErrors (moe_reward.py:57,218-219) and the build's loud failures"""
     from mj_video_amd import synth
