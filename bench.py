@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=4, help="pairs per GPU per step (BASELINE.json configs[1]: 4)")
     ap.add_argument("--image-size", type=int, default=448)
-    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=8, help="tiles per video (frames x tiles per frame; configs[3]: 16 x 7 = 112)")
     ap.add_argument("--streams", type=int, default=2, help="sample groups scored concurrently on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -180,12 +180,21 @@ def main():
         if prof:
             res = ops.prof_results()
 
+            traffic = {}
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if (S, F, args.pairs) == (448, 8, 4) and os.path.isfile(tpath):
+                traffic = json.load(open(tpath)).get("per_launch_bytes", {})
+
             def roofline(res, steps):
                 tot = sum(r["ms"] for r in res.values())
                 name, r = max(res.items(), key=lambda kv: kv[1]["ms"])
                 tfl = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
                 return {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4),
+                        # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same workload
+                        # (profiles/r01_pmc_traffic.json; a PMC run cannot be nested inside this process)
+                        "traffic": traffic.get(name),
+                        "algorithmic_bytes_per_launch": round(r["bytes"] / max(r["launches"], 1)),
                         "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(r["launches"], 1), 4),
                         "share_of_kernel_time": round(r["ms"] / tot, 4) if tot else None}
 

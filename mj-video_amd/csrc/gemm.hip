@@ -534,30 +534,33 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
       if (m_main >= d->M) m_main = d->M;
     }
   }
+  static const char* const tags256[] = {"gemm256_bias", "gemm256_bias_gelu", "gemm256_bias_relu", "gemm256_scale_res",
+                                        "gemm256_silu_mul"};
+  static const char* const tags128[] = {"gemm128_bias", "gemm128_bias_gelu", "gemm128_bias_relu", "gemm128_scale_res",
+                                        "gemm128_silu_mul"};
+  if (d->epilogue < 0 || d->epilogue > 4) {
+    mjv_set_error("gemm: unknown epilogue %d", d->epilogue);
+    return MJV_E_ARG;
+  }
+  // one profiler scope per kernel launch, named like the kernel rocprofv3 reports (t256::gemm256_kernel<EPI> / t128::...)
   auto run = [&](GemmArgs g, bool use_big) -> int {
+    const double frac = (double)g.M / (double)d->M;
+    MjvProfScope ps(use_big ? tags256[d->epilogue] : tags128[d->epilogue], s, flops * frac, bytes * frac);
     switch (d->epilogue) {
       case MJV_EPI_BIAS: return launch<MJV_EPI_BIAS>(g, s, use_big);
       case MJV_EPI_BIAS_GELU: return launch<MJV_EPI_BIAS_GELU>(g, s, use_big);
       case MJV_EPI_BIAS_RELU: return launch<MJV_EPI_BIAS_RELU>(g, s, use_big);
       case MJV_EPI_SCALE_RES: return launch<MJV_EPI_SCALE_RES>(g, s, use_big);
-      case MJV_EPI_SILU_MUL: return launch<MJV_EPI_SILU_MUL>(g, s, use_big);
-      default: mjv_set_error("gemm: unknown epilogue %d", d->epilogue); return MJV_E_ARG;
+      default: return launch<MJV_EPI_SILU_MUL>(g, s, use_big);
     }
   };
-  static const char* const tags[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_relu", "gemm_scale_res", "gemm_silu_mul"};
-  if (d->epilogue < 0 || d->epilogue > 4) {
-    mjv_set_error("gemm: unknown epilogue %d", d->epilogue);
-    return MJV_E_ARG;
-  }
-  MjvProfScope ps(tags[d->epilogue], s, flops, bytes);
   if (m_main == d->M) return run(a, big);
   GemmArgs head = a;
   head.M = m_main;
   int rc = run(head, true);
   if (rc) return rc;
-  // tail rows [m_main, M): the epilogue row maps depend on the absolute row index only through
-  // res_mod / out_group, both of which are periodic in m; shifting by a multiple of 256 rows keeps them exact only
-  // if the period divides m_main, so the tail kernel gets the absolute offset folded into its pointers instead.
+  // tail rows [m_main, M): the kernel indexes A relative to the shifted pointer and adds m_base back for the output /
+  // residual row maps, which depend on the absolute row
   GemmArgs tail = a;
   tail.M = d->M - m_main;
   tail.A = a.A + (long)m_main * a.lda;

@@ -347,3 +347,29 @@ def test_gemm_tail_peeling_is_invisible(cuda):
     ref2 = ((a2.float() @ w2.float().t()).view(-1, P, 2048) + table[1:].float()).to(BF)
     got = out.view(-1, P + 1, 2048)
     assert torch.equal(got[:, 1:], ref2) and (got[:, 0] == 0).all()
+
+
+def test_attention_long_context_c4(cuda):
+    """BASELINE.json configs[3] shape: one causal sequence of 28 837 tokens (16 frames x 7 tiles x 256 + text), D=128 GQA.
+    The eager reference would need a 28.8k x 28.8k score matrix per head; the fp32 reference here is evaluated in query
+    chunks for the first/last/middle rows of two heads."""
+    from mj_video_amd import ops
+    D, H, G, L = 128, 2, 2, 28837
+    q, k, v = rnd(L, H * D, seed=1), rnd(L, D, seed=2), rnd(L, D, seed=3)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    out = torch.empty(L, H * D, dtype=BF, device=cuda)
+    scale = D ** -0.5
+    ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), out, cu.to(cuda), L, H, G, D, True, scale, 1)
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    rows = torch.cat([torch.arange(0, 70), torch.arange(14000, 14130), torch.arange(L - 200, L)])
+    kf, vf = k.float(), v.float()
+    for h in range(H):
+        sc = q[rows, h * D:(h + 1) * D].float() @ kf.t()
+        sc = (sc.to(BF).float() * scale).to(BF).float()
+        sc = sc.masked_fill(torch.arange(L)[None, :] > rows[:, None], float("-inf"))
+        ref = (torch.softmax(sc, -1).to(BF).float() @ vf).to(BF).float()
+        got = o[rows, h * D:(h + 1) * D]
+        rel = (got - ref).norm() / ref.norm()
+        assert rel.item() < 6e-3, (h, rel.item())
+        assert (got - ref).abs().max().item() < 0.03
