@@ -247,28 +247,43 @@ constexpr int GELU_BYTES = MJV_GELU_TABLE_LEN * 2;
 constexpr int LDS_BYTES = EPI_TILE_BYTES + GELU_BYTES;  // 140704 B >= PIPE_BYTES: one workgroup per CU either way
 static_assert(LDS_BYTES >= PIPE_BYTES && LDS_BYTES <= 160 * 1024 && EPI_TILE_BYTES % 16 == 0, "LDS budget");
 
-// stage half-tile number n (order per K-tile: W rows 0-127, W rows 128-255, A rows 0-127, A rows 128-255)
-MJV_DEV void stage_half(const GemmArgs& p, int n, int nk, int m0, int n0, char* smem, int wave, int lane) {
-  const int t = n >> 2, which = n & 3;
+// per-lane global source pointers of the two 1-KiB DMA pieces a wave issues for each of the four half-tiles
+// (W rows 0-127, W rows 128-255, A rows 0-127, A rows 128-255) at k = 0: the row clamp and the chunk swizzle are loop
+// invariant, so a stage is two {pointer + k offset, global_load_lds} pairs - the DMA issue sits in the load segment that
+// has to hide under the partner wave's 16-MFMA segment
+struct StagePtrs {
+  const u16* src[4][2];
+};
+
+MJV_DEV void init_stage_ptrs(StagePtrs& sp, const GemmArgs& p, int m0, int n0, int wave, int lane) {
+#pragma unroll
+  for (int which = 0; which < 4; ++which) {
+    const bool is_w = which < 2;
+    const u16* base = is_w ? p.W : p.A;
+    const long ld = is_w ? p.ldw : p.lda;
+    const int row0 = (is_w ? n0 : m0) + (which & 1) * 128;
+    const int max_row = (is_w ? p.N : p.M) - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wave * 2 + i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (r & 7);
+      int gr = row0 + r;
+      gr = gr < max_row ? gr : max_row;
+      sp.src[which][i] = base + (long)gr * ld + c * 8;
+    }
+  }
+}
+
+// stage half-tile WHICH of K-tile t (no-op past the last K-tile)
+template <int WHICH>
+MJV_DEV void stage_half(const StagePtrs& sp, int t, int nk, char* smem, int wave) {
   if (t >= nk) return;
-  const bool is_w = which < 2;
-  const u16* __restrict__ src = is_w ? p.W : p.A;
-  const long ld = is_w ? p.ldw : p.lda;
-  const int row0 = (is_w ? n0 : m0) + (which & 1) * 128;
-  const int max_row = (is_w ? p.N : p.M) - 1;
-  char* dst = smem + ((t & 1) * 4 + which) * HALF_BYTES;
+  char* dst = smem + ((t & 1) * 4 + WHICH) * HALF_BYTES + wave * 2048;
   const int k0 = t * BK;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int piece = wave * 2 + i;
-    const int r = piece * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
-    int gr = row0 + r;
-    gr = gr < max_row ? gr : max_row;
-    const u16* g = src + (long)gr * ld + k0 + c * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
-  }
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp.src[WHICH][i] + k0),
+                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
 }
 
 #define MJV_BARRIER()                      \
@@ -278,7 +293,9 @@ MJV_DEV void stage_half(const GemmArgs& p, int n, int nk, int m0, int n0, char* 
     __builtin_amdgcn_sched_barrier(0);     \
   } while (0)
 
-template <int EPI>
+// VAR 0: the DMA of a phase is issued in its load segment (before the first barrier);
+// VAR 1: in the middle of its MFMA segment, where the issue slots are otherwise idle behind the matrix pipe
+template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -308,9 +325,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const int a_half = 2 + wr;   // this wave's activation half-tile index within a K-tile
   const int w_half = wc >> 1;  // this wave's weight half-tile index
 
+  StagePtrs sp;
+  init_stage_ptrs(sp, p, m0, n0, wave, lane);
   // ---- prologue: K-tile 0 completely, W halves of K-tile 1
-#pragma unroll
-  for (int n = 0; n < 6; ++n) stage_half(p, n, nk, m0, n0, smem, wave, lane);
+  stage_half<0>(sp, 0, nk, smem, wave);
+  stage_half<1>(sp, 0, nk, smem, wave);
+  stage_half<2>(sp, 0, nk, smem, wave);
+  stage_half<3>(sp, 0, nk, smem, wave);
+  stage_half<0>(sp, 1, nk, smem, wave);
+  stage_half<1>(sp, 1, nk, smem, wave);
   if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   MJV_BARRIER();
@@ -324,51 +347,66 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #define MJV_LOAD_W(NS)                                                                          \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
       wf[NS][j][kk] = *(const bf16x8*)(wbase + ((NS) * 32 + j * 16) * 128 + w_off[kk]);
-#define MJV_MFMA(MS, NS)                                                                                  \
-  __builtin_amdgcn_s_setprio(1);                                                                          \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)          \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(MS) * 4 + i][(NS) * 2 + j] =                     \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NS][j][kk], af[i][kk], acc[(MS) * 4 + i][(NS) * 2 + j], 0, 0, 0); \
+#define MJV_MFMA_K(MS, NS, KK)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)             \
+      acc[(MS) * 4 + i][(NS) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+          wf[NS][j][KK], af[i][KK], acc[(MS) * 4 + i][(NS) * 2 + j], 0, 0, 0);
+// 16 MFMAs; STAGE_STMT runs in the load segment (VAR 0, see callers) or between the two k-steps (VAR 1)
+#define MJV_MFMA(MS, NS, STAGE_STMT)                   \
+  __builtin_amdgcn_s_setprio(1);                       \
+  MJV_MFMA_K(MS, NS, 0)                                \
+  if constexpr (VAR == 1) {                            \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    STAGE_STMT;                                        \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  }                                                    \
+  MJV_MFMA_K(MS, NS, 1)                                \
   __builtin_amdgcn_s_setprio(0);
 
   for (int t = 0; t < nk; ++t) {
     const char* abase = smem + ((t & 1) * 4 + a_half) * HALF_BYTES;
     const char* wbase = smem + ((t & 1) * 4 + w_half) * HALF_BYTES;
-    const int g = 4 * t;
     // phase 1: quadrant (0,0)
     MJV_LOAD_W(0)
     MJV_LOAD_A(0)
-    stage_half(p, g + 6, nk, m0, n0, smem, wave, lane);
+    if constexpr (VAR == 0) stage_half<2>(sp, t + 1, nk, smem, wave);   // A rows 0-127 of K-tile t+1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
-    MJV_MFMA(0, 0)
+    MJV_MFMA(0, 0, stage_half<2>(sp, t + 1, nk, smem, wave))
     MJV_BARRIER();
     // phase 2: quadrant (0,1)
     MJV_LOAD_W(1)
-    stage_half(p, g + 7, nk, m0, n0, smem, wave, lane);
+    if constexpr (VAR == 0) stage_half<3>(sp, t + 1, nk, smem, wave);   // A rows 128-255 of K-tile t+1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
-    MJV_MFMA(0, 1)
+    MJV_MFMA(0, 1, stage_half<3>(sp, t + 1, nk, smem, wave))
     MJV_BARRIER();
     // phase 3: quadrant (1,1)
     MJV_LOAD_A(1)
-    stage_half(p, g + 8, nk, m0, n0, smem, wave, lane);
+    if constexpr (VAR == 0) stage_half<0>(sp, t + 2, nk, smem, wave);   // W rows 0-127 of K-tile t+2
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
-    MJV_MFMA(1, 1)
+    MJV_MFMA(1, 1, stage_half<0>(sp, t + 2, nk, smem, wave))
     MJV_BARRIER();
-    // phase 4: quadrant (1,0); retire K-tile t+1 (everything but the 2 half-tiles of t+2 issued last)
-    stage_half(p, g + 9, nk, m0, n0, smem, wave, lane);
-    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // phase 4: quadrant (1,0); retire K-tile t+1: everything but the half-tiles of K-tile t+2 issued since
+    // (VAR 0: W0 and W1 = 4 DMA instructions; VAR 1: only W0 = 2, W1 follows inside this phase's MFMA segment)
+    if constexpr (VAR == 0) {
+      stage_half<1>(sp, t + 2, nk, smem, wave);                         // W rows 128-255 of K-tile t+2
+      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     MJV_BARRIER();
-    MJV_MFMA(1, 0)
+    MJV_MFMA(1, 0, stage_half<1>(sp, t + 2, nk, smem, wave))
     MJV_BARRIER();
   }
   if (wr == 0) MJV_BARRIER();  // matches the stagger barrier of the second M-group
 #undef MJV_LOAD_A
 #undef MJV_LOAD_W
 #undef MJV_MFMA
+#undef MJV_MFMA_K
 
   // ---- epilogue, two passes through LDS (the pipeline buffers are dead: every DMA was retired by the last
   // vmcnt(0) and the last ds_read is 5 barriers back):
@@ -461,19 +499,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
 int g_num_cus = 256;
+int g_variant = 0;  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
 
 template <int EPI>
 int launch(GemmArgs a, hipStream_t s, bool big) {
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     attr_done = true;
   }
   if (big) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
-    hipLaunchKernelGGL(t256::gemm256_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+    if (g_variant == 1)
+      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+    else
+      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
   } else {
     a.tiles_m = (a.M + 127) / 128;
     a.tiles_n = (a.N + 127) / 128;
@@ -485,6 +528,11 @@ int launch(GemmArgs a, hipStream_t s, bool big) {
 }  // namespace
 
 extern "C" int mjv_gemm_set_tile(int32_t tile) {
+  if (tile >= 1000 && tile < 1010) {  // 1000 + v: keep the automatic tile choice, switch the 256-kernel variant
+    g_variant = tile - 1000;
+    g_force_tile = 0;
+    return MJV_OK;
+  }
   if (tile != 0 && tile != 128 && tile != 256) {
     mjv_set_error("gemm_set_tile: %d not in {0,128,256}", tile);
     return MJV_E_ARG;

@@ -319,6 +319,7 @@ class InternVLChatRewardModeling(nn.Module):
         self._rope: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.last_packed34: Optional[torch.Tensor] = None
         self._ws_tag = "g0"
+        self._host_cache = None
         self._streams: List[torch.cuda.Stream] = []
         self.n_streams = 2  # sample groups scored concurrently on separate HIP streams (1 = single stream)
         self.debug_probes: Optional[Dict[str, torch.Tensor]] = None  # tests set {} to capture per-layer states
@@ -431,8 +432,21 @@ class InternVLChatRewardModeling(nn.Module):
         return t[:need].view(rows, cols)
 
     # -- host-side analysis of the token ids (the reference does this with ids.tolist(), moe_reward.py:242)
-    def _analyse_ids(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], n_tiles: int):
+    def _host_ids(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]):
+        """Token ids / mask as host numpy arrays: ONE device->host copy per forward (none for CPU tensors, none when the
+        same unmodified tensors are passed again).  The reference does the same round trip with ``ids.tolist()``
+        (moe_reward.py:242); everything the kernels need from the ids (row maps, lengths) is derived on the host."""
+        def key(t):
+            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype)
+        k = (key(input_ids), key(attention_mask))
+        if self._host_cache is not None and self._host_cache[0] == k:
+            return self._host_cache[1], self._host_cache[2]
         ids = input_ids.detach().to("cpu").numpy()
+        am = None if attention_mask is None else attention_mask.detach().to("cpu").numpy().astype(bool)
+        self._host_cache = (k, ids, am)
+        return ids, am
+
+    def _analyse_ids(self, ids: np.ndarray, am: Optional[np.ndarray], n_tiles: int):
         if ids.ndim != 2:
             raise ValueError(f"input_ids must be [batch, seq], got {ids.shape}")
         B, N = ids.shape
@@ -442,8 +456,7 @@ class InternVLChatRewardModeling(nn.Module):
         ctx_id = self.model.img_context_token_id
         if ctx_id is None:
             raise ValueError("model.model.img_context_token_id is not set (eval_genai_mjvideo.py:115)")
-        if attention_mask is not None:
-            am = attention_mask.detach().to("cpu").numpy().astype(bool)
+        if am is not None:
             if am.shape != ids.shape:
                 raise ValueError(f"attention_mask shape {am.shape} != input_ids shape {ids.shape}")
             lens = am.sum(axis=1)
@@ -592,7 +605,7 @@ class InternVLChatRewardModeling(nn.Module):
         """Scores samples [lo, lo+B) of the batch on the CURRENT stream with its own workspace ``tag``."""
         dev = pixel_values.device
         self._ws_tag = tag
-        info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])
+        info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])  # host arrays (see forward)
         B, total = info["B"], info["total"]
         lc = self.config.llm_config
         hdim = lc.hidden_size
@@ -653,7 +666,7 @@ class InternVLChatRewardModeling(nn.Module):
         hd.packed34 = outs["packed34"][lo:].data_ptr()
         ops.reward_heads(hd)
 
-    def _split_batch(self, input_ids: torch.Tensor, n_tiles: int, groups: int):
+    def _split_batch(self, input_ids: np.ndarray, n_tiles: int, groups: int):
         """[(sample_lo, sample_hi, tile_lo, tile_hi)] - contiguous sample groups with their pixel tiles."""
         B = input_ids.shape[0]
         groups = max(1, min(groups, B))
@@ -661,7 +674,7 @@ class InternVLChatRewardModeling(nn.Module):
             return [(0, B, 0, n_tiles)]
         ctx = self.model.img_context_token_id
         per = self.model.num_image_token
-        counts = (input_ids.detach().to("cpu") == ctx).sum(dim=1).tolist()
+        counts = (input_ids == ctx).sum(axis=1).tolist()
         tiles = [c // per for c in counts]
         out, s0, t0 = [], 0, 0
         for g in range(groups):
@@ -710,14 +723,15 @@ class InternVLChatRewardModeling(nn.Module):
             aspect_scores=torch.empty(B, nasp, dtype=torch.float32, device=dev),
             score=torch.empty(B, dtype=torch.float32, device=dev),
             packed34=torch.empty(B, 1 + nasp + nobj, dtype=torch.float32, device=dev))
+        ids_h, am_h = self._host_ids(input_ids, attention_mask)
         n_groups = 1 if self.debug_probes is not None else self.n_streams
         # shared lazily-built tables must exist before the streams fork
         self._rope_tables(int(input_ids.shape[1]), dev)
         if pixel_values.shape[-1] % self.config.vision_config.patch_size == 0:
             self._pos_table(d, pixel_values.shape[-1] // self.config.vision_config.patch_size, dev)
-        groups = self._split_batch(input_ids, pixel_values.shape[0], n_groups)
+        groups = self._split_batch(ids_h, pixel_values.shape[0], n_groups)
         if len(groups) == 1:
-            self._forward_group(d, "g0", pixel_values, input_ids, attention_mask, outs, 0, True)
+            self._forward_group(d, "g0", pixel_values, ids_h, am_h, outs, 0, True)
         else:
             # independent sample groups on separate HIP streams: one group's GEMM tail / attention overlaps the
             # other's kernels on otherwise idle CUs; per-sample math is unchanged (packing is per sample)
@@ -730,8 +744,8 @@ class InternVLChatRewardModeling(nn.Module):
                 st = self._streams[gi]
                 st.wait_event(fork)
                 with torch.cuda.stream(st):
-                    self._forward_group(d, f"g{gi}", pixel_values[t0:t1], input_ids[s0:s1],
-                                        None if attention_mask is None else attention_mask[s0:s1], outs, s0, False)
+                    self._forward_group(d, f"g{gi}", pixel_values[t0:t1], ids_h[s0:s1],
+                                        None if am_h is None else am_h[s0:s1], outs, s0, False)
                     done = torch.cuda.Event()
                     done.record(st)
                 main.wait_event(done)

@@ -191,19 +191,19 @@ def test_analyse_ids_packing():
     model.model.img_context_token_id = synth.IMG_CONTEXT_ID
     a, b = synth.synth_input_ids(16, 1), synth.synth_input_ids(8, 2)
     ids, mask = synth.pad_batch([a, b])
-    info = model._analyse_ids(ids, mask, 6)
+    info = model._analyse_ids(ids.numpy(), mask.numpy().astype(bool), 6)
     assert info["cu"].tolist() == [0, a.shape[1], a.shape[1] + b.shape[1]]
     assert info["sel_rows"].tolist() == [a.shape[1] - 1, a.shape[1] + b.shape[1] - 1, a.shape[1] - 5, a.shape[1] + b.shape[1] - 5]
     assert (info["ids"][info["img_rows"]] == synth.IMG_CONTEXT_ID).all() and info["img_rows"].size == 24
     assert info["positions"][a.shape[1]] == 0
     with pytest.raises(ValueError, match="IMG_CONTEXT"):
-        model._analyse_ids(ids, mask, 5)
+        model._analyse_ids(ids.numpy(), mask.numpy().astype(bool), 5)
     left = torch.flip(mask, dims=[1])
     with pytest.raises(NotImplementedError, match="right-padded"):
-        model._analyse_ids(ids, left, 6)
+        model._analyse_ids(ids.numpy(), left.numpy().astype(bool), 6)
     model.model.img_context_token_id = None
     with pytest.raises(ValueError, match="img_context_token_id"):
-        model._analyse_ids(ids, mask, 6)
+        model._analyse_ids(ids.numpy(), mask.numpy().astype(bool), 6)
 
 
 def test_custom_output_access():
