@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
 
     const int k0 = kt * KB;
     if (CAUSAL && k0 > q0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
+    if (q0 >= len) continue;               // wave-uniform: this wave has no query (ragged last q-block, e.g. 1025 = 8*128 + 1):
+                                           // it only helps staging K/V and keeps the barriers balanced
 
     // ---- S^T = K Q^T : two 32-key sub-tiles
     f32x16 sacc[2];

@@ -295,8 +295,11 @@ MJV_DEV void stage_half(const StagePtrs& sp, int t, int nk, char* smem, int wave
     __builtin_amdgcn_sched_barrier(0);     \
   } while (0)
 
-// VAR 0: the DMA of a phase is issued in its load segment (before the first barrier);
-// VAR 1: in the middle of its MFMA segment, where the issue slots are otherwise idle behind the matrix pipe
+// VAR 0: production.  VAR 3 / 4: timing experiments (no epilogue / no global stores) used to attribute the epilogue's
+// cost; selected with mjv_gemm_set_tile(1000 + VAR), never by the automatic path.
+// Tried and rejected on this structure (A/B in one process, tools/gemm_bench.py): issuing the LDS-DMA in the middle of
+// the MFMA segment instead of the load segment (-5 %); a persistent role-split form where 4 waves issue all DMA and the
+// other 4 all global stores so that stores never sit in front of a vmcnt wait (-5...-35 %: spills + half-width pass B).
 template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -353,15 +356,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)             \
       acc[(MS) * 4 + i][(NS) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
           wf[NS][j][KK], af[i][KK], acc[(MS) * 4 + i][(NS) * 2 + j], 0, 0, 0);
-// 16 MFMAs; STAGE_STMT runs in the load segment (VAR 0, see callers) or between the two k-steps (VAR 1)
-#define MJV_MFMA(MS, NS, STAGE_STMT)                   \
+#define MJV_MFMA(MS, NS)                               \
   __builtin_amdgcn_s_setprio(1);                       \
   MJV_MFMA_K(MS, NS, 0)                                \
-  if constexpr (VAR == 1) {                            \
-    __builtin_amdgcn_sched_barrier(0);                 \
-    STAGE_STMT;                                        \
-    __builtin_amdgcn_sched_barrier(0);                 \
-  }                                                    \
   MJV_MFMA_K(MS, NS, 1)                                \
   __builtin_amdgcn_s_setprio(0);
 
@@ -371,37 +368,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // phase 1: quadrant (0,0)
     MJV_LOAD_W(0)
     MJV_LOAD_A(0)
-    if constexpr (VAR != 1) stage_half<2>(sp, t + 1, nk, smem, wave);   // A rows 0-127 of K-tile t+1
+    stage_half<2>(sp, t + 1, nk, smem, wave);   // A rows 0-127 of K-tile t+1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
-    MJV_MFMA(0, 0, stage_half<2>(sp, t + 1, nk, smem, wave))
+    MJV_MFMA(0, 0)
     MJV_BARRIER();
     // phase 2: quadrant (0,1)
     MJV_LOAD_W(1)
-    if constexpr (VAR != 1) stage_half<3>(sp, t + 1, nk, smem, wave);   // A rows 128-255 of K-tile t+1
+    stage_half<3>(sp, t + 1, nk, smem, wave);   // A rows 128-255 of K-tile t+1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
-    MJV_MFMA(0, 1, stage_half<3>(sp, t + 1, nk, smem, wave))
+    MJV_MFMA(0, 1)
     MJV_BARRIER();
     // phase 3: quadrant (1,1)
     MJV_LOAD_A(1)
-    if constexpr (VAR != 1) stage_half<0>(sp, t + 2, nk, smem, wave);   // W rows 0-127 of K-tile t+2
+    stage_half<0>(sp, t + 2, nk, smem, wave);   // W rows 0-127 of K-tile t+2
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
-    MJV_MFMA(1, 1, stage_half<0>(sp, t + 2, nk, smem, wave))
+    MJV_MFMA(1, 1)
     MJV_BARRIER();
-    // phase 4: quadrant (1,0); retire K-tile t+1: everything but the half-tiles of K-tile t+2 issued since
-    // (VAR 0: W0 and W1 = 4 DMA instructions; VAR 1: only W0 = 2, W1 follows inside this phase's MFMA segment)
-    if constexpr (VAR != 1) {
-      stage_half<1>(sp, t + 2, nk, smem, wave);                         // W rows 128-255 of K-tile t+2
-      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // phase 4: quadrant (1,0); retire K-tile t+1 (everything but the 2 half-tiles of t+2 issued last)
+    stage_half<1>(sp, t + 2, nk, smem, wave);                         // W rows 128-255 of K-tile t+2
+    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MJV_BARRIER();
-    MJV_MFMA(1, 0, stage_half<1>(sp, t + 2, nk, smem, wave))
+    MJV_MFMA(1, 0)
     MJV_BARRIER();
   }
   if (wr == 0) MJV_BARRIER();  // matches the stagger barrier of the second M-group
@@ -748,6 +739,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p, int n_tile
 #undef MJV_LOAD_W
 #undef MJV_MFMA
 }
+
 }  // namespace t256
 
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
@@ -760,7 +752,6 @@ int launch(GemmArgs a, hipStream_t s, bool big) {
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::P_LDS_BYTES);
@@ -777,8 +768,6 @@ int launch(GemmArgs a, hipStream_t s, bool big) {
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
     else if (g_variant == 3)
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
-    else if (g_variant == 1)
-      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
     else
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
   } else {
