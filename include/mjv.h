@@ -168,6 +168,19 @@ typedef struct mjv_heads_desc {
 
 int mjv_reward_heads_bf16(const mjv_heads_desc* d, void* stream);
 
+/* Frame preprocessing of load_video on the GPU (scripts/data_processor/data.py:56-64,81-117,158-179):
+ * decoded uint8 RGB frames [n_frames][height][width][3] -> Pillow-bit-exact bicubic resize to out_w x out_h (two passes,
+ * uint8 intermediate `tmp` [n_frames][height][out_w][3]) -> crop into tile_size^2 tiles (row-major grid) ->
+ * ((u8/255) - mean) / std in fp32 -> bf16, written to out[(frame * tiles_per_frame + tile_offset + tile)][3][S][S].
+ * xbounds/ybounds = (first tap, tap count) per output column / row, xcoef/ycoef = 22-bit fixed-point taps
+ * [out][kx|ky], computed on the host exactly as Pillow does (mj-video_amd/video.py: pil_resample_coeffs).
+ * mean / stdv are HOST pointers to 3 floats. */
+int mjv_resize_normalize_u8(const uint8_t* frames, int32_t n_frames, int32_t height, int32_t width, int32_t out_w,
+                            int32_t out_h, const int32_t* xbounds, const int32_t* xcoef, int32_t kx,
+                            const int32_t* ybounds, const int32_t* ycoef, int32_t ky, uint8_t* tmp, mjv_bf16* out,
+                            int32_t tile_size, int32_t tiles_per_frame, int32_t tile_offset, const float* mean,
+                            const float* stdv, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Opt-in profiler: when enabled, every launch is bracketed by hipEvents recorded on ITS stream.
  * mjv_prof_collect synchronises those events and accumulates per-kernel-tag time; used by bench.py

@@ -68,6 +68,8 @@ SYMBOLS = {
     "mjv_cls_rows_bf16": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _I32, _I32, _VP]),
     "mjv_embed_gather_bf16": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _I32, _I32, _I32, _I32, _VP]),
     "mjv_reward_heads_bf16": (C.c_int, [C.POINTER(HeadsDesc), _VP]),
+    "mjv_resize_normalize_u8": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _I32, _I32,
+                                           _I32, C.POINTER(C.c_float), C.POINTER(C.c_float), _VP]),
     "mjv_prof_enable": (C.c_int, [_I32]),
     "mjv_prof_reset": (C.c_int, []),
     "mjv_prof_collect": (C.c_int, []),

@@ -94,3 +94,65 @@ def score_pair_batch(model, config, tokenizer, examples: Sequence[dict], generat
     ids_b, mask = pad_right(ids, pad_id)
     model.forward(torch.cat(px).to(dev), ids_b.to(dev), mask.to(dev))
     return model.last_packed34.view(len(examples), 2, -1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Collator batch format and MJ-BENCH-VIDEO label schema
+@torch.no_grad()
+def score_collated_batch(model, batch: dict):
+    """Scores one batch in the training collator's layout (scripts/data_processor/dataset.py:445-554 as consumed by
+    scripts/train/overall_train.py:70-82): ``video_{0,1}_pixel_values [B, F, 3, H, W]``, right-padded
+    ``video_{0,1}_input_ids [B, N]`` and ``video_{0,1}_attention_mask``.  The 5-D pixel block is flattened to
+    ``[B*F, 3, H, W]`` exactly as the trainer does; both videos of every pair go through one packed forward.
+    Returns ``(output_video_0, output_video_1)`` (CustomOutput each)."""
+    dev = model.model.device
+    outs = []
+    px = [batch[f"video_{i}_pixel_values"] for i in (0, 1)]
+    b, f, c, h, w = px[0].shape
+    flat = torch.cat([p.reshape(-1, c, h, w) for p in px]).to(torch.bfloat16).to(dev)
+    ids = [batch[f"video_{i}_input_ids"] for i in (0, 1)]
+    n = max(int(t.shape[1]) for t in ids)
+    pad = model.config.pad_token_id
+    if pad is None:
+        raise ValueError("model.config.pad_token_id must be set for collated batches (dataset.py pads with it)")
+
+    def widen(t, fill):
+        if t.shape[1] == n:
+            return t
+        extra = torch.full((t.shape[0], n - t.shape[1]), fill, dtype=t.dtype, device=t.device)
+        return torch.cat([t, extra], dim=1)
+
+    ids_all = torch.cat([widen(t, pad) for t in ids])
+    mask_all = torch.cat([widen(batch[f"video_{i}_attention_mask"], 0) for i in (0, 1)])
+    out = model.forward(flat, ids_all.to(dev), mask_all.to(dev))
+    from .modeling import CustomOutput
+    from dataclasses import fields
+    for i in (0, 1):
+        sl = slice(i * b, (i + 1) * b)
+        outs.append(CustomOutput(**{fl.name: getattr(out, fl.name)[sl] for fl in fields(CustomOutput)}))
+    return outs[0], outs[1]
+
+
+def criteria_targets(labels: dict, mse: bool = True):
+    """MJ-BENCH-VIDEO per-criterion labels -> (score, relevance, names): 1 = good -> (+1, relevant), 2 = bad ->
+    (-1 with ``mse`` else 0, relevant), anything else -> (0, irrelevant)   (dataset.py:52-85)."""
+    score, related, names = [], [], []
+    for key, value in labels.items():
+        names.append(key)
+        score.append(1 if value == 1 else ((-1 if mse else 0) if value == 2 else 0))
+        related.append(1 if value in (1, 2) else 0)
+    return score, related, names
+
+
+def overall_target(value, mse: bool = True):
+    """Same mapping for a single overall label (dataset.py:57-69)."""
+    return ([1], [1]) if value == 1 else (([-1 if mse else 0], [1]) if value == 2 else ([0], [0]))
+
+
+def preference_targets(labels):
+    """"Video 1 better" -> (0, counted), "Video 2 better" -> (1, counted), anything else -> (1, masked out)
+    (dataset.py:87-112); ``labels`` is a dict of per-aspect strings or a single overall string."""
+    values = list(labels.values()) if isinstance(labels, dict) else [labels]
+    pref = [0 if v == "Video 1 better" else 1 for v in values]
+    mask = [1 if v in ("Video 1 better", "Video 2 better") else 0 for v in values]
+    return pref, mask

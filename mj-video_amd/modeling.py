@@ -436,14 +436,16 @@ class InternVLChatRewardModeling(nn.Module):
         """Token ids / mask as host numpy arrays: ONE device->host copy per forward (none for CPU tensors, none when the
         same unmodified tensors are passed again).  The reference does the same round trip with ``ids.tolist()``
         (moe_reward.py:242); everything the kernels need from the ids (row maps, lengths) is derived on the host."""
-        def key(t):
-            return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype)
-        k = (key(input_ids), key(attention_mask))
-        if self._host_cache is not None and self._host_cache[0] == k:
-            return self._host_cache[1], self._host_cache[2]
+        c = self._host_cache
+        if (c is not None and c[0] is input_ids and c[1] == input_ids._version and c[2] is attention_mask
+                and (attention_mask is None or c[3] == attention_mask._version)):
+            return c[4], c[5]
         ids = input_ids.detach().to("cpu").numpy()
         am = None if attention_mask is None else attention_mask.detach().to("cpu").numpy().astype(bool)
-        self._host_cache = (k, ids, am)
+        # the cache holds the tensors themselves: an address-based key could match a NEW tensor that the allocator
+        # placed where a freed one used to live
+        self._host_cache = (input_ids, input_ids._version, attention_mask,
+                            None if attention_mask is None else attention_mask._version, ids, am)
         return ids, am
 
     def _analyse_ids(self, ids: np.ndarray, am: Optional[np.ndarray], n_tiles: int):

@@ -187,7 +187,7 @@ def synth_input_ids(n_image_tokens: int, caption_seed: int, n_caption: int = 32,
     ids += cap + list(GATING_PATTERN)
     t = torch.tensor(ids, dtype=torch.long).unsqueeze(0)
     if not interleave_frames:
-        assert t.shape[1] == n_image_tokens + N_TEXT_TOKENS, t.shape
+        assert t.shape[1] == n_image_tokens + N_TEXT_TOKENS - 32 + n_caption, t.shape
     return t
 
 

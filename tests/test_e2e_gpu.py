@@ -246,3 +246,25 @@ def test_error_behaviour(cuda):
     model.config.pad_token_id = None
     b = model.forward(px, ids.to(cuda), torch.ones_like(ids).to(cuda)).score.item()
     assert a == b
+
+
+def test_collated_batch_layout(cuda):
+    """the training collator's batch layout ([B,F,3,H,W] pixels, right-padded ids, two videos per pair) scored in one
+    packed forward == the two videos scored separately"""
+    from mj_video_amd import harness, synth
+    from mj_video_amd.chat_input import num_image_tokens_per_tile
+    cfg = make_cfg("tiny", 56)
+    model = build_hip_model(cfg, synth.synth_state_dict(cfg, seed=9, dtype=torch.float32), cuda)
+    B, Fr = 3, 4
+    per = num_image_tokens_per_tile(cfg) * Fr
+    batch = {}
+    for i in (0, 1):
+        batch[f"video_{i}_pixel_values"] = torch.stack([synth.synth_pixel_values(5, 10 * i + b, Fr, 56) for b in range(B)])
+        ids, mask = synth.pad_batch([synth.synth_input_ids(per, 20 + b, n_caption=32 - 3 * b * i) for b in range(B)], length=per + 150)
+        batch[f"video_{i}_input_ids"], batch[f"video_{i}_attention_mask"] = ids, mask
+    o0, o1 = harness.score_collated_batch(model, batch)
+    for i, o in ((0, o0), (1, o1)):
+        ref = model.forward(batch[f"video_{i}_pixel_values"].reshape(-1, 3, 56, 56).to(cuda), batch[f"video_{i}_input_ids"].to(cuda),
+                            batch[f"video_{i}_attention_mask"].to(cuda))
+        for f in FIELDS:
+            assert torch.equal(getattr(o, f), getattr(ref, f)), (i, f)

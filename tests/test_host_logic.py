@@ -264,6 +264,19 @@ def test_load_frames_normalisation_and_order():
         video.load_video("http://example.com/x.mp4")
 
 
+def test_pil_resize_restatement_is_bit_exact():
+    """the integer restatement that feeds the GPU preprocessing kernel reproduces Pillow's own bicubic resize bit for bit
+    (down- and up-scaling, both axes, identity)"""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for (H, W, ow, oh) in [(360, 640, 448, 448), (96, 128, 448, 448), (270, 480, 896, 448), (448, 448, 448, 448), (500, 333, 448, 896)]:
+        img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh)))
+        assert np.array_equal(video.pil_resize_u8(img, ow, oh), ref), (H, W, ow, oh)
+    b, k = video.pil_resample_coeffs(1280, 448)
+    assert k.shape == (448, 13) and b[0].tolist() == [0, 7] and int(k[100].sum()) in range((1 << 22) - 8, (1 << 22) + 8)
+
+
 # ----------------------------------------------------------------------------------------- harness
 def test_preference_protocol():
     votes = [("rightvote", 0.1, 0.5), ("rightvote", 0.5, 0.1), ("leftvote", 0.3, -0.2), ("bothbad_vote", -1.0, -0.1),
@@ -271,6 +284,21 @@ def test_preference_protocol():
     c = harness.evaluate_votes(votes)
     assert (c.prefer_truth, c.prefer_total, c.truth, c.total) == (2, 4, 4, 8)
     assert c.prefer_acc == 0.5 and c.acc == 0.5
+
+
+def test_label_schema_mappings():
+    assert harness.criteria_targets({"a": 1, "b": 2, "c": 0, "d": 3}) == ([1, -1, 0, 0], [1, 1, 0, 0], ["a", "b", "c", "d"])
+    assert harness.criteria_targets({"a": 2}, mse=False)[0] == [0]
+    assert harness.overall_target(1) == ([1], [1]) and harness.overall_target(2) == ([-1], [1]) and harness.overall_target(0) == ([0], [0])
+    assert harness.preference_targets({"x": "Video 1 better", "y": "Video 2 better", "z": "tie"}) == ([0, 1, 1], [1, 1, 0])
+    assert harness.preference_targets("Video 2 better") == ([1], [1])
+    # the label file shipped with the reference parses with these rules
+    import json
+    path = "/root/reference/datas/test.json"
+    if os.path.isfile(path):
+        rec = json.load(open(path))[0]
+        s, r, names = harness.criteria_targets(rec["video_0_label"])
+        assert len(s) == len(r) == len(names) == 28 and set(s) <= {-1, 0, 1}
 
 
 def test_shard_bounds_cover_everything():

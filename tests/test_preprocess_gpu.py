@@ -1,0 +1,50 @@
+"""GPU frame preprocessing against the host path: Pillow resize -> tiles -> ToTensor/Normalize ->
+bf16.  Byte/integer work up to the normalisation, so the bar is BIT-EXACT."""
+import numpy as np
+import pytest
+import torch
+
+from mj_video_amd import video
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("H,W,max_num,expect_tiles", [
+    (720, 1280, 1, 1),      # the eval driver's setting: max_num=1, one 448^2 tile per frame (eval_genai_mjvideo.py:130)
+    (480, 854, 1, 1),
+    (448, 448, 1, 1),       # identity resize
+    (300, 200, 1, 1),       # up-scaling
+    (720, 1280, 6, 3),      # 2x1 grid + thumbnail
+    (896, 1344, 6, 7),      # 3x2 grid + thumbnail (BASELINE.json configs[3] shape)
+])
+def test_device_preprocessing_is_bit_exact(cuda, H, W, max_num, expect_tiles):
+    rng = np.random.default_rng(H * 7 + W)
+    F = 3
+    # smooth content + noise, so the resize is not averaging pure noise
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = []
+    for f in range(F):
+        base = 127 + 100 * np.sin(xx / (17.0 + f) + yy / 29.0)[..., None] * np.array([1.0, 0.7, -0.8])
+        frames.append(np.clip(base + rng.normal(0, 20, size=(H, W, 3)), 0, 255).astype(np.uint8))
+    ref, counts = video.load_frames(frames, input_size=448, max_num=max_num)
+    assert counts == [expect_tiles] * F
+    got, gcounts = video.load_frames_device(torch.from_numpy(np.stack(frames)).to(cuda), input_size=448, max_num=max_num)
+    assert gcounts == counts and got.dtype == torch.bfloat16 and got.shape == ref.shape
+    assert torch.equal(got.cpu(), ref.to(torch.bfloat16))
+
+
+def test_device_preprocessing_feeds_the_model(cuda):
+    """uint8 frames -> device preprocessing -> reward forward: same scores as the host-preprocessed path (bitwise)"""
+    from util import build_hip_model, make_cfg
+    from mj_video_amd import synth
+    from mj_video_amd.chat_input import num_image_tokens_per_tile
+    cfg = make_cfg("tiny", 56)
+    model = build_hip_model(cfg, synth.synth_state_dict(cfg, seed=4, dtype=torch.float32), cuda)
+    rng = np.random.default_rng(1)
+    frames = [rng.integers(0, 256, size=(120, 160, 3), dtype=np.uint8) for _ in range(4)]
+    host, _ = video.load_frames(frames, input_size=56, max_num=1)
+    devp, _ = video.load_frames_device(torch.from_numpy(np.stack(frames)), input_size=56, max_num=1)
+    ids = synth.synth_input_ids(num_image_tokens_per_tile(cfg) * 4, 2).to(cuda)
+    a = model.forward(host.to(torch.bfloat16).to(cuda), ids, None).score
+    b = model.forward(devp, ids, None).score
+    assert torch.equal(a, b)
