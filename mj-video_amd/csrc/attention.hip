@@ -248,11 +248,233 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ software-pipelined form
+// Same math, different schedule: the QK^T MFMAs of tile t+1 are issued BEFORE the softmax of tile t, so the matrix pipe
+// works under the VALU-heavy softmax of the same wave (two score tiles live in registers), K and V are double-buffered
+// in LDS with K running one tile ahead of V, and there is ONE barrier per tile:
+//   iteration t:  issue global loads K(t+2), V(t+1) -> registers
+//                 S_next = K(t+1) Q^T           (LDS K slot (t+1)&1, written during iteration t-1)
+//                 softmax(S_cur) -> P, rescale  (VALU, overlaps the MFMAs above)
+//                 O^T += V(t)^T P^T             (LDS V slot t&1, written during iteration t-1)
+//                 registers -> LDS: K(t+2) into K slot t&1 (K(t) was last read in iteration t-1),
+//                                   V(t+1) into V slot (t+1)&1 (V(t-1) was last read in iteration t-1)
+//                 barrier
+template <int D, bool CAUSAL, int RM>
+__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(AttnArgs p) {
+  using C = Cfg<D>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (C::K_BYTES + C::V_BYTES)];
+  char* Kbuf[2] = {smem, smem + C::K_BYTES};
+  char* Vbuf[2] = {smem + 2 * C::K_BYTES, smem + 2 * C::K_BYTES + C::V_BYTES};
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int seq = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+  const int s0 = p.cu[seq];
+  const int len = p.cu[seq + 1] - s0;
+  if (qb * QB >= len) return;
+  const int kvh = head / p.kv_group;
+  const int q0 = qb * QB + wave * 32;
+  const int qi = q0 + l31;
+  const int qrow = s0 + (qi < len ? qi : len - 1);
+  const bool wave_on = q0 < len;
+
+  bf16x8 qf[D / 16];
+  {
+    const u16* qp = p.Q + (long)qrow * p.ldq + (long)head * p.qhs + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+  f32x16 oacc[D / 32];
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int kv_end = CAUSAL ? min(len, (qb + 1) * QB) : len;
+  const int n_tiles = (kv_end + KB - 1) / KB;
+  const u16* Kg = p.K + (long)kvh * p.khs;
+  const u16* Vg = p.V + (long)kvh * p.vhs;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float c_exp = (RM == RM_POW2) ? p.scale * LOG2E : LOG2E;
+
+  u32x4 kreg[C::LOADS], vreg[C::LOADS];
+  auto load_k = [&](int kt) {
+#pragma unroll
+    for (int c = 0; c < C::LOADS; ++c) {
+      const int idx = tid + c * 256;
+      int kr = kt * KB + idx / C::CHUNKS;
+      kr = kr < len ? kr : len - 1;
+      kreg[c] = *(const u32x4*)(Kg + (long)(s0 + kr) * p.ldk + (idx % C::CHUNKS) * 8);
+    }
+  };
+  auto load_v = [&](int kt) {
+#pragma unroll
+    for (int c = 0; c < C::LOADS; ++c) {
+      const int idx = tid + c * 256;
+      int kr = kt * KB + idx / C::CHUNKS;
+      kr = kr < len ? kr : len - 1;
+      vreg[c] = *(const u32x4*)(Vg + (long)(s0 + kr) * p.ldv + (idx % C::CHUNKS) * 8);
+    }
+  };
+  auto store_k = [&](char* Ks) {
+#pragma unroll
+    for (int c = 0; c < C::LOADS; ++c) {
+      const int idx = tid + c * 256;
+      *(u32x4*)(Ks + (idx / C::CHUNKS) * C::KP + (idx % C::CHUNKS) * 16) = kreg[c];
+    }
+  };
+  auto store_v = [&](char* Vs) {
+#pragma unroll
+    for (int c = 0; c < C::LOADS; ++c) {
+      const int idx = tid + c * 256;
+      *(u32x4*)(Vs + (idx / C::CHUNKS) * C::VP + (idx % C::CHUNKS) * 16) = vreg[c];
+    }
+  };
+  auto qk = [&](const char* Ks, f32x16 (&sacc)[2]) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[t2][r] = 0.f;
+      const char* kp = Ks + (t2 * 32 + l31) * C::KP + hi * 16;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kp + ks * 32);
+        sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t2], 0, 0, 0);
+      }
+    }
+  };
+  // softmax of one score tile + PV with the matching V tile
+  auto softmax_pv = [&](f32x16 (&sacc)[2], const char* Vs, int k0) {
+    const bool need_mask = (k0 + KB > len) || (CAUSAL && (k0 + KB - 1 > q0));
+    if (need_mask) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= len || (CAUSAL && key > qi)) sacc[t2][r] = -INFINITY;
+        }
+    }
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[t2][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, round_score<RM>(mx, p.scale));
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      m_run = m_new;
+    }
+    const f32x2 c2 = {c_exp, c_exp};
+    const f32x2 nmb2 = {-m_run * c_exp, -m_run * c_exp};
+    f32x2 psum2 = {0.f, 0.f};
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      unsigned pw[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 a2 = {sacc[t2][r], sacc[t2][r + 1]};
+        f32x2 sr = round_pair(a2);
+        if constexpr (RM == RM_MUL) sr = round_pair(a2 * f32x2{p.scale, p.scale});
+        if constexpr (RM == RM_DIV) sr = round_pair(sr * f32x2{p.scale, p.scale});
+        const f32x2 e2 = sr * c2 + nmb2;
+        const f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+        psum2 += pv;
+        pw[r >> 1] = pack_pair(pv);
+      }
+      pf[t2][0] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+      pf[t2][1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
+    }
+    float psum = psum2[0] + psum2[1];
+    psum += __shfl_xor(psum, 32, 64);
+    l_run += psum;
+    const int g16 = (lane >> 4) & 1, li = lane & 15;
+    const int trow = li >> 2, tcol = 4 * (li & 3);
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int kbase = t2 * 32 + s2 * 16 + 4 * hi + trow;
+          const char* vp = Vs + kbase * C::VP + (dt * 32 + g16 * 16 + tcol) * 2;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * C::VP));
+          s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf[t2][s2], oacc[dt], 0, 0, 0);
+        }
+  };
+  auto tile_on = [&](int t) { return wave_on && t < n_tiles && !(CAUSAL && t * KB > q0 + 31); };
+
+  // ---- prologue: K(0), V(0), K(1) resident; S(0) computed
+  load_k(0);
+  load_v(0);
+  store_k(Kbuf[0]);
+  store_v(Vbuf[0]);
+  if (n_tiles > 1) {
+    load_k(1);
+    store_k(Kbuf[1]);
+  }
+  __syncthreads();
+  f32x16 sA[2], sB[2];
+  if (tile_on(0)) qk(Kbuf[0], sA);
+
+  // two tiles per trip so the score registers are addressed statically (sA <-> even tiles, sB <-> odd tiles)
+  for (int t = 0; t < n_tiles; t += 2) {
+    // ---------------- even tile t: scores in sA
+    if (t + 2 < n_tiles) load_k(t + 2);
+    if (t + 1 < n_tiles) load_v(t + 1);
+    if (tile_on(t + 1)) qk(Kbuf[1], sB);
+    if (tile_on(t)) softmax_pv(sA, Vbuf[0], t * KB);
+    if (t + 2 < n_tiles) store_k(Kbuf[0]);
+    if (t + 1 < n_tiles) store_v(Vbuf[1]);
+    __syncthreads();
+    if (t + 1 >= n_tiles) break;
+    // ---------------- odd tile t+1: scores in sB
+    if (t + 3 < n_tiles) load_k(t + 3);
+    if (t + 2 < n_tiles) load_v(t + 2);
+    if (tile_on(t + 2)) qk(Kbuf[0], sA);
+    if (tile_on(t + 1)) softmax_pv(sB, Vbuf[1], (t + 1) * KB);
+    if (t + 3 < n_tiles) store_k(Kbuf[1]);
+    if (t + 2 < n_tiles) store_v(Vbuf[0]);
+    __syncthreads();
+  }
+
+  if (qi < len) {
+    const float inv = 1.0f / l_run;
+    u16* op = p.O + (long)(s0 + qi) * p.ldo + (long)head * p.ohs;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 v = {pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
+                   pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv)};
+        *(u32x2*)(op + dt * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+int g_attn_variant = 0;  // 0 = attn_kernel, 1 = attn_pipe_kernel (A/B in one process)
+
 template <int D, bool CAUSAL>
 int launch(const AttnArgs& a, int n_seqs, int max_seqlen, hipStream_t s) {
   dim3 grid((max_seqlen + QB - 1) / QB, a.n_heads, n_seqs);
   int e;
   const bool pow2 = a.round_mode == 0 && frexpf(a.scale, &e) == 0.5f;
+  if (g_attn_variant == 1) {
+    if (a.round_mode == 1) hipLaunchKernelGGL((attn_pipe_kernel<D, CAUSAL, RM_DIV>), grid, dim3(256), 0, s, a);
+    else if (pow2) hipLaunchKernelGGL((attn_pipe_kernel<D, CAUSAL, RM_POW2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_pipe_kernel<D, CAUSAL, RM_MUL>), grid, dim3(256), 0, s, a);
+    return mjv_check_launch("attention");
+  }
   if (a.round_mode == 1) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV>), grid, dim3(256), 0, s, a);
   else if (pow2) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_POW2>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_MUL>), grid, dim3(256), 0, s, a);
@@ -260,6 +482,15 @@ int launch(const AttnArgs& a, int n_seqs, int max_seqlen, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int mjv_attention_set_variant(int32_t v) {
+  if (v != 0 && v != 1) {
+    mjv_set_error("attention_set_variant: %d not in {0,1}", v);
+    return MJV_E_ARG;
+  }
+  g_attn_variant = v;
+  return MJV_OK;
+}
 
 extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
   MJV_REQUIRE(d && d->Q && d->K && d->V && d->O && d->cu_seqlens, "attention: null pointer");

@@ -87,6 +87,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     return out
 
 
+def attention_set_variant(v: int) -> None:
+    check(load_library().mjv_attention_set_variant(v), "mjv_attention_set_variant")
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float,
               rows: Optional[int] = None, gather_grid: int = 0) -> torch.Tensor:
     _chk_bf16(x, gamma, beta, out)

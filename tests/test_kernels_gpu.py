@@ -224,6 +224,15 @@ def test_patchify_cls_embed(cuda):
 
 
 # ------------------------------------------------------------------------------------------ attention
+@pytest.fixture(params=[0, 1])
+def attn_variant(request, cuda):
+    """both attention schedules (plain / software-pipelined) on every attention test"""
+    from mj_video_amd import ops
+    ops.attention_set_variant(request.param)
+    yield request.param
+    ops.attention_set_variant(0)
+
+
 def attn_reference(q, k, v, lens, H, G, D, causal, scale, mode):
     """fp32 reference with the reference's score rounding; q [N, H*D], k/v [N, (H/G)*D] packed."""
     out = torch.zeros(q.shape[0], H * D)
@@ -251,7 +260,7 @@ def attn_reference(q, k, v, lens, H, G, D, causal, scale, mode):
     (128, 4, 2, True, [650, 131, 64, 1]),
     (128, 16, 2, True, [2186]),
 ])
-def test_attention(cuda, D, H, G, causal, lens):
+def test_attention(cuda, attn_variant, D, H, G, causal, lens):
     from mj_video_amd import ops
     N = sum(lens)
     KVH = H // G
@@ -273,7 +282,7 @@ def test_attention(cuda, D, H, G, causal, lens):
     assert_close_bf16(out, ref, 2, atol=0.02, what="attention")
 
 
-def test_attention_exact_selection(cuda):
+def test_attention_exact_selection(cuda, attn_variant):
     """one-hot softmax (a huge score on one key): output must equal that key's V row bit for bit; checks the
     key<->value pairing of the transposed LDS reads and the causal/ragged masks"""
     from mj_video_amd import ops
@@ -349,7 +358,7 @@ def test_gemm_tail_peeling_is_invisible(cuda):
     assert torch.equal(got[:, 1:], ref2) and (got[:, 0] == 0).all()
 
 
-def test_attention_long_context_c4(cuda):
+def test_attention_long_context_c4(cuda, attn_variant):
     """BASELINE.json configs[3] shape: one causal sequence of 28 837 tokens (16 frames x 7 tiles x 256 + text), D=128 GQA.
     The eager reference would need a 28.8k x 28.8k score matrix per head; the fp32 reference here is evaluated in query
     chunks for the first/last/middle rows of two heads."""
