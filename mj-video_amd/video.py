@@ -200,17 +200,24 @@ def load_frames_device(frames_u8: torch.Tensor, input_size=448, max_num=1):
     return out, [per_frame] * F
 
 
-def load_video(video_path, bound=None, input_size=448, max_num=1, num_segments=32):
-    """Drop-in for data.py:158-179.  URLs are not fetched (no network in this build): pass a local path."""
+def decode_frames(video_path, bound=None, num_segments=32) -> np.ndarray:
+    """The decode half of data.py:158-179: ``num_segments`` uniformly sampled RGB frames as one uint8 array [F, H, W, 3].
+    URLs are not fetched (no network in this build): pass a local path."""
     if str(video_path).startswith("http"):
         raise RuntimeError("this build has no network access: download the video and pass a local path")
     try:
         from decord import VideoReader, cpu
     except ImportError as e:  # same hard dependency as the reference (data.py:4)
-        raise ImportError("load_video needs the 'decord' package to decode video files; "
-                          "use load_frames() with already-decoded frames otherwise") from e
+        raise ImportError("decoding video files needs the 'decord' package; "
+                          "use load_frames() / load_frames_device() with already-decoded frames otherwise") from e
     vr = VideoReader(str(Path(video_path)), ctx=cpu(0), num_threads=1)
     max_frame = len(vr) - 1
     fps = float(vr.get_avg_fps())
     idx = get_index(bound, fps, max_frame, first_idx=0, num_segments=num_segments)
-    return load_frames([vr[int(i)].asnumpy() for i in idx], input_size=input_size, max_num=max_num)
+    return np.stack([vr[int(i)].asnumpy() for i in idx])
+
+
+def load_video(video_path, bound=None, input_size=448, max_num=1, num_segments=32):
+    """Drop-in for data.py:158-179 (host path: PIL resize + normalise)."""
+    frames = decode_frames(video_path, bound=bound, num_segments=num_segments)
+    return load_frames(list(frames), input_size=input_size, max_num=max_num)

@@ -209,4 +209,4 @@ if __name__ == "__main__":
     elif a.what == "rankset_c1":
         gen_rankset("rankset_c1", 224, a.pairs, wseed=0, pixel_seed=400, fp32_every=4)
     elif a.what == "rankset_c2":
-        gen_rankset("rankset_c2", 448, a.pairs, wseed=0, pixel_seed=500, fp32_every=0)
+        gen_rankset("rankset_c2", 448, a.pairs, wseed=0, pixel_seed=500, fp32_every=8)

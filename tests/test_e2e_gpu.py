@@ -268,3 +268,43 @@ def test_collated_batch_layout(cuda):
                             batch[f"video_{i}_attention_mask"].to(cuda))
         for f in FIELDS:
             assert torch.equal(getattr(o, f), getattr(ref, f)), (i, f)
+
+
+def test_eval_driver_protocol(cuda):
+    """scripts/eval/eval_genai_mjvideo.py: batched scoring of (caption, left, right, vote) examples through
+    prepare_chat_input + device preprocessing gives the same scores as the reference's protocol (one forward per video,
+    batch 1) and the same prefer_Acc / Acc bookkeeping"""
+    import importlib.util
+    import numpy as np
+    from util import ROOT
+    from mj_video_amd import harness, synth, video
+    from mj_video_amd.chat_input import prepare_chat_input, video_prefix
+    from test_host_logic import StubTokenizer
+    spec = importlib.util.spec_from_file_location("eval_driver", f"{ROOT}/scripts/eval/eval_genai_mjvideo.py")
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    cfg = make_cfg("tiny", 56)
+    model = build_hip_model(cfg, synth.synth_state_dict(cfg, seed=31, dtype=torch.float32), cuda)
+    tok = StubTokenizer()
+    rng = np.random.default_rng(5)
+    store = {f"v{i}": rng.integers(0, 256, size=(4, 90, 120, 3), dtype=np.uint8) for i in range(10)}
+    votes = ["leftvote", "rightvote", "tievote", "bothbad_vote", "rightvote"]
+    examples = [dict(prompt=f"a synthetic caption number {i}", left_video=f"v{2 * i}", right_video=f"v{2 * i + 1}",
+                     vote_type=votes[i]) for i in range(5)]
+
+    def loader(name):
+        return video.load_frames_device(torch.from_numpy(store[name]).to(cuda), input_size=56, max_num=1)[0]
+
+    counts, scores = drv.evaluate_examples(model, cfg, tok, examples, loader, pairs_per_batch=2)
+    ref = harness.PreferenceCounts()
+    for i, ex in enumerate(examples):
+        s = []
+        for side in ("left_video", "right_video"):
+            pv = loader(ex[side])
+            ids, mask = prepare_chat_input(cfg, tok, pv, video_prefix(pv.shape[0]) + ex["prompt"], {}, device=cuda)
+            s.append(model.forward(pv, ids, mask).score[0].item())
+        assert s[0] == scores[i, 0, 0].item() and s[1] == scores[i, 1, 0].item()
+        ref.update(ex["vote_type"], s[0], s[1])
+    assert (counts.prefer_truth, counts.prefer_total, counts.truth, counts.total) == \
+        (ref.prefer_truth, ref.prefer_total, ref.truth, ref.total)
+    assert counts.total == 5 and counts.prefer_total == 3
