@@ -63,6 +63,12 @@ struct GemmArgs {
 
 MJV_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+MJV_DEV unsigned pack2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+
 MJV_DEV long out_row_of(const GemmArgs& p, int m) {
   if (p.out_rows) return p.out_rows[m];
   if (p.out_group > 0) {
@@ -297,9 +303,11 @@ MJV_DEV void stage_half(const StagePtrs& sp, int t, int nk, char* smem, int wave
 
 // VAR 0: production.  VAR 3 / 4: timing experiments (no epilogue / no global stores) used to attribute the epilogue's
 // cost; selected with mjv_gemm_set_tile(1000 + VAR), never by the automatic path.
-// Tried and rejected on this structure (A/B in one process, tools/gemm_bench.py): issuing the LDS-DMA in the middle of
-// the MFMA segment instead of the load segment (-5 %); a persistent role-split form where 4 waves issue all DMA and the
-// other 4 all global stores so that stores never sit in front of a vmcnt wait (-5...-35 %: spills + half-width pass B).
+// Tried and rejected on this structure (A/B in one process, tools/gemm_bench.py; code in git history): issuing the
+// LDS-DMA in the middle of the MFMA segment instead of the load segment (-5 %); a persistent one-workgroup-per-CU form
+// that prefetches the next tile's first K-tile under the epilogue (neutral: s_waitcnt vmcnt is in-order, the first DMA
+// wait also waits for the epilogue's stores); a role-split persistent form where 4 waves issue all DMA and the other 4
+// all global stores (-5...-35 %: spills + half-width pass B).
 template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
         col = nl;
       }
-      const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};   // one v_cvt_pk_bf16_f32 per pair
       *(u32x2*)(etile + ml * EPI_PITCH + col * 2) = o;
     }
   }
@@ -481,19 +489,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         rsv[it] = u32x4{0u, 0u, 0u, 0u};
         if (m0 + ml < p.M && n < nlim) {
           const int m = p.m_base + m0 + ml;
-          const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;
+          const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;   // uniform branch
           rsv[it] = *(const u32x4*)(p.res + rrow * p.ldr + n);
         }
       }
     }
     __syncthreads();
+    // plain row mapping (output row == residual row == m) is the common case: keep the integer divisions of the
+    // row maps (CLS slot / pos-emb period / <IMG_CONTEXT> scatter) out of it
+    const bool plain = !p.out_rows && p.out_group <= 0 && p.res_mod <= 0;
+    u16* crow = p.C + (long)(p.m_base + m0 + ml0) * p.ldc + n;
+    const long cstep = (long)ROWS_PER_PASS * p.ldc;
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
       const int ml = it * ROWS_PER_PASS + ml0;
       if (m0 + ml >= p.M || n >= nlim) continue;
-      const int m = p.m_base + m0 + ml;
       u32x4 val = *(const u32x4*)(etile + ml * EPI_PITCH + c8 * 2);
-      const long orow = out_row_of(p, m);
       if constexpr (EPI == MJV_EPI_SCALE_RES) {
         float v[8], rs[8];
         unpack8(val, v);
@@ -504,240 +515,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         unpack8(rsv[it], rs);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rs[e];
-        val = pack8(v);
+        val = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
       }
+      u16* dst = plain ? crow + it * cstep : p.C + out_row_of(p, p.m_base + m0 + ml) * p.ldc + n;
       if constexpr (VAR == 4) {
-        asm volatile("" ::"v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]));
+        asm volatile("" ::"v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(dst));
       } else {
         // streaming (nt) stores for the short-K GEMMs with large outputs: their store bursts otherwise evict the
         // operand panels the XCD's CUs share from its 4 MiB L2 (measured +5-7 % on the ViT K = 1024 GEMMs, neutral
         // to slightly negative on the LLM shapes, which therefore keep plain stores)
-        if (p.nt_store) __builtin_nontemporal_store(val, (u32x4*)(p.C + orow * p.ldc + n));
-        else *(u32x4*)(p.C + orow * p.ldc + n) = val;
+        if (p.nt_store) __builtin_nontemporal_store(val, (u32x4*)dst);
+        else *(u32x4*)dst = val;
       }
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------------ persistent form
-// One workgroup per CU walks tiles vb = cta, cta + grid, ... (same XCD-aware order as the one-tile-per-workgroup
-// launch: grid is a multiple of 8, so a CU keeps its XCD's share of the list).  What it buys over gemm256_kernel:
-// the first K-tile of the NEXT tile is DMA'd into LDS before the current tile's epilogue runs, and the epilogue's
-// global stores drain under the next main loop instead of under a workgroup launch.  LDS (all 160 KiB):
-//   [ 96K,160K) pipeline buffer 0      [32K, 96K) pipeline buffer 1
-//   [  0, 66K) epilogue half-tile (128 rows x 528 B), [66K, 71.4K) GELU table - both inside buffer 1 / below buffer 0,
-//   which are idle while an epilogue runs, so buffer 0 can already receive the next tile's K-tile 0.
-constexpr int P_BUF0 = 96 * 1024, P_BUF1 = 32 * 1024;
-constexpr int P_EPI_HALF_BYTES = 128 * EPI_PITCH;
-constexpr int P_LDS_BYTES = 160 * 1024;
-static_assert(P_EPI_HALF_BYTES + GELU_BYTES <= P_BUF0 && P_BUF1 + 4 * HALF_BYTES <= P_BUF0, "persistent LDS layout");
-
-template <int WHICH>
-MJV_DEV void stage_half_p(const StagePtrs& sp, int t, int nk, char* smem, int wave) {
-  if (t >= nk) return;
-  char* dst = smem + ((t & 1) ? P_BUF1 : P_BUF0) + WHICH * HALF_BYTES + wave * 2048;
-  const int k0 = t * BK;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp.src[WHICH][i] + k0),
-                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p, int n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int nk = p.K / BK;
-  const int sw = l15 & 7;
-  int a_off[2], w_off[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    a_off[kk] = l15 * 128 + (((kk * 4 + l4) ^ sw) << 4);
-    w_off[kk] = ((wc & 1) * 64 + l15) * 128 + (((kk * 4 + l4) ^ sw) << 4);
-  }
-  const int a_half = 2 + wr, w_half = wc >> 1;
-
-  int vb = blockIdx.x;
-  if (vb >= n_tiles) return;
-  int tm, tn;
-  tile_of_vblock(p, n_tiles, vb, tm, tn);
-  StagePtrs sp;
-  init_stage_ptrs(sp, p, tm * BM, tn * BN, wave, lane);
-  stage_half_p<0>(sp, 0, nk, smem, wave);
-  stage_half_p<1>(sp, 0, nk, smem, wave);
-  stage_half_p<2>(sp, 0, nk, smem, wave);
-  stage_half_p<3>(sp, 0, nk, smem, wave);
-
-  bf16x8 af[4][2], wf[2][2][2];
-#define MJV_LOAD_A(MS)                                                                          \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
-      af[i][kk] = *(const bf16x8*)(abase + ((MS) * 64 + i * 16) * 128 + a_off[kk]);
-#define MJV_LOAD_W(NS)                                                                          \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
-      wf[NS][j][kk] = *(const bf16x8*)(wbase + ((NS) * 32 + j * 16) * 128 + w_off[kk]);
-#define MJV_MFMA(MS, NS)                                                                                  \
-  __builtin_amdgcn_s_setprio(1);                                                                          \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)          \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(MS) * 4 + i][(NS) * 2 + j] =                     \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NS][j][kk], af[i][kk], acc[(MS) * 4 + i][(NS) * 2 + j], 0, 0, 0); \
-  __builtin_amdgcn_s_setprio(0);
-
-  for (;;) {
-    const int m0 = tm * BM, n0 = tn * BN;
-    // K-tile 0 of this tile is in flight or landed (issued above / under the previous tile's epilogue)
-    stage_half_p<0>(sp, 1, nk, smem, wave);
-    stage_half_p<1>(sp, 1, nk, smem, wave);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MJV_BARRIER();
-    if (wr == 1) MJV_BARRIER();
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int t = 0; t < nk; ++t) {
-      const char* tb = smem + ((t & 1) ? P_BUF1 : P_BUF0);
-      const char* abase = tb + a_half * HALF_BYTES;
-      const char* wbase = tb + w_half * HALF_BYTES;
-      MJV_LOAD_W(0)
-      MJV_LOAD_A(0)
-      stage_half_p<2>(sp, t + 1, nk, smem, wave);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      MJV_BARRIER();
-      MJV_MFMA(0, 0)
-      MJV_BARRIER();
-      MJV_LOAD_W(1)
-      stage_half_p<3>(sp, t + 1, nk, smem, wave);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      MJV_BARRIER();
-      MJV_MFMA(0, 1)
-      MJV_BARRIER();
-      MJV_LOAD_A(1)
-      stage_half_p<0>(sp, t + 2, nk, smem, wave);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      MJV_BARRIER();
-      MJV_MFMA(1, 1)
-      MJV_BARRIER();
-      stage_half_p<1>(sp, t + 2, nk, smem, wave);
-      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      MJV_BARRIER();
-      MJV_MFMA(1, 0)
-      MJV_BARRIER();
-    }
-    if (wr == 0) MJV_BARRIER();
-
-    // ---- next tile: pointers + K-tile 0 into buffer 0 (idle: the last ds_read of either buffer is >= 3 barriers back)
-    const int vb_next = vb + gridDim.x;
-    const bool more = vb_next < n_tiles;
-    int tm_n = 0, tn_n = 0;
-    if (more) {
-      tile_of_vblock(p, n_tiles, vb_next, tm_n, tn_n);
-      init_stage_ptrs(sp, p, tm_n * BM, tn_n * BN, wave, lane);
-      stage_half_p<0>(sp, 0, nk, smem, wave);
-      stage_half_p<1>(sp, 0, nk, smem, wave);
-      stage_half_p<2>(sp, 0, nk, smem, wave);
-      stage_half_p<3>(sp, 0, nk, smem, wave);
-    }
-
-    // ---- epilogue in two 128-row halves through LDS (pass A: fragment layout -> bf16 tile; pass B: coalesced rows)
-    char* etile = smem;
-    u16* gtab = (u16*)(smem + P_EPI_HALF_BYTES);
-    if constexpr (EPI == MJV_EPI_BIAS_GELU) {
-      for (int c = tid; c < MJV_GELU_TABLE_LEN / 8; c += 512) ((u32x4*)gtab)[c] = ((const u32x4*)g_gelu_table)[c];
-    }
-    constexpr int OUT_COLS = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
-    constexpr int LANES_PER_ROW = OUT_COLS / 8;
-    constexpr int ROWS_PER_PASS = 512 / LANES_PER_ROW;
-    const int c8 = (tid % LANES_PER_ROW) * 8;
-    const int nout0 = (EPI == MJV_EPI_SILU_MUL) ? n0 / 2 : n0;
-    const int nlim = (EPI == MJV_EPI_SILU_MUL) ? p.N / 2 : p.N;
-    const int n = nout0 + c8;
-    float sc[8];
-    if constexpr (EPI == MJV_EPI_SCALE_RES) {
-      if (p.scale && n < nlim) unpack8(*(const u32x4*)(p.scale + n), sc);
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      __syncthreads();  // GELU table visible / previous half's pass B done
-      if (wr == h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int nl = wc * 64 + j * 16 + l4 * 4;
-          float b4[4] = {0.f, 0.f, 0.f, 0.f};
-          if (EPI != MJV_EPI_SILU_MUL && p.bias && n0 + nl < p.N) {
-            const u32x2 bb = *(const u32x2*)(p.bias + n0 + nl);
-            b4[0] = __uint_as_float(bb[0] << 16);
-            b4[1] = __uint_as_float(bb[0] & 0xffff0000u);
-            b4[2] = __uint_as_float(bb[1] << 16);
-            b4[3] = __uint_as_float(bb[1] & 0xffff0000u);
-          }
-          if (EPI == MJV_EPI_SILU_MUL && (j & 1)) continue;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float v[4];
-            int col;
-            if constexpr (EPI == MJV_EPI_SILU_MUL) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = rbf(silu(rbf(acc[i][j][r]))) * rbf(acc[i][j + 1][r]);
-              col = wc * 32 + (j >> 1) * 16 + l4 * 4;
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + b4[r];
-              if constexpr (EPI == MJV_EPI_BIAS_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_lut(rbf(v[r]), gtab);
-              } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-              }
-              col = nl;
-            }
-            const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            *(u32x2*)(etile + (i * 16 + l15) * EPI_PITCH + col * 2) = o;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll 4
-      for (int r0 = 0; r0 < 128; r0 += ROWS_PER_PASS) {
-        const int ml = r0 + tid / LANES_PER_ROW;
-        const int mrel = m0 + h * 128 + ml;
-        if (mrel >= p.M || n >= nlim) continue;
-        const int m = p.m_base + mrel;
-        u32x4 val = *(const u32x4*)(etile + ml * EPI_PITCH + c8 * 2);
-        const long orow = out_row_of(p, m);
-        if constexpr (EPI == MJV_EPI_SCALE_RES) {
-          float v[8], rs[8];
-          unpack8(val, v);
-          if (p.scale) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * sc[e]);
-          }
-          const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;
-          unpack8(*(const u32x4*)(p.res + rrow * p.ldr + n), rs);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rs[e];
-          val = pack8(v);
-        }
-        *(u32x4*)(p.C + orow * p.ldc + n) = val;
-      }
-    }
-    if (!more) break;
-    __syncthreads();  // pass B of the second half read the staging tile that buffer 1 is about to overwrite
-    vb = vb_next;
-    tm = tm_n;
-    tn = tn_n;
-  }
-#undef MJV_LOAD_A
-#undef MJV_LOAD_W
-#undef MJV_MFMA
 }
 
 }  // namespace t256
@@ -754,17 +545,12 @@ int launch(GemmArgs a, hipStream_t s, bool big) {
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)t256::gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::P_LDS_BYTES);
     attr_done = true;
   }
   if (big) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
-    if (g_variant == 2) {
-      const int n_tiles = a.tiles_m * a.tiles_n;
-      const int grid = n_tiles < g_num_cus ? n_tiles : g_num_cus;
-      hipLaunchKernelGGL((t256::gemm256p_kernel<EPI>), dim3(grid), dim3(512), t256::P_LDS_BYTES, s, a, n_tiles);
-    } else if (g_variant == 4)
+    if (g_variant == 4)
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
     else if (g_variant == 3)
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
