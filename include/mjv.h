@@ -104,8 +104,8 @@ typedef struct mjv_attn_desc {
 } mjv_attn_desc;
 
 int mjv_attention_bf16(const mjv_attn_desc* d, void* stream);
-/* kernel schedule: 0 = one score tile in flight, 1 = software-pipelined (QK^T of tile t+1 under the softmax of tile t,
- * double-buffered K/V, one barrier per tile); identical arithmetic, used for A/B measurements and by the parity tests */
+/* kernel schedule selector for A/B measurements; only 0 (the production schedule) is built in at present, any other
+ * value returns MJV_E_ARG */
 int mjv_attention_set_variant(int32_t variant);
 
 /* LayerNorm over the last dim, fp32 statistics, bf16 out (nn.LayerNorm on bf16:

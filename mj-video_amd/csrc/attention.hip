@@ -25,7 +25,33 @@ struct AttnArgs {
   int causal;
   float scale;
   int round_mode;
+  int n_qb, n_seqs;   // q-blocks per sequence (of the launched kernel's block size), sequences
 };
+
+// Workgroup -> (sequence, head, q-block).  The grid is one-dimensional and hardware hands consecutive workgroup ids to
+// the 8 XCDs round-robin, each XCD with its own L2; all q-blocks of one (sequence, kv head) - and, under GQA, of every
+// q head that shares that kv head - read the same K and V, so they are given consecutive slots of ONE XCD and K / V come
+// from HBM once instead of once per q-block (measured before this mapping: 2.29 GB fetched per ViT attention launch
+// against 0.40 GB of q, k, v).
+struct BlockId {
+  int seq, head, qb;
+  bool valid;
+};
+MJV_DEV BlockId decode_block(const AttnArgs& p) {
+  const int total = p.n_qb * p.n_heads * p.n_seqs;
+  const int per_xcd = (total + 7) >> 3;
+  const int b = blockIdx.x;
+  const int v = (b & 7) * per_xcd + (b >> 3);
+  BlockId id;
+  id.valid = v < total;
+  id.qb = v % p.n_qb;
+  const int r = v / p.n_qb;
+  const int g = r % p.kv_group, r2 = r / p.kv_group;
+  const int n_kv = p.n_heads / p.kv_group;
+  id.head = (r2 % n_kv) * p.kv_group + g;
+  id.seq = r2 / n_kv;
+  return id;
+}
 
 constexpr int QB = 128;  // queries per workgroup
 constexpr int KB = 64;   // keys per tile
@@ -57,6 +83,16 @@ MJV_DEV f32x2 round_pair(f32x2 v) {
   return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
 }
 
+// value of the partner lane (lane ^ 32) combined with one's own, through one v_permlane32_swap (no LDS round trip)
+MJV_DEV float xhalf_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+MJV_DEV float xhalf_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int RM>
 MJV_DEV float round_score(float a, float scale) {
   if constexpr (RM == RM_MUL) return rbf(a * scale);
@@ -65,15 +101,19 @@ MJV_DEV float round_score(float a, float scale) {
 }
 
 template <int D, bool CAUSAL, int RM>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p) {
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[C::K_BYTES + C::V_BYTES];
   char* Ks = smem;
   char* Vs = smem + C::K_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every branch on it below is wave-uniform
   const int l31 = lane & 31, hi = lane >> 5;
-  const int seq = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+  const BlockId bid = decode_block(p);
+  if (!bid.valid) return;
+  // causal: the q-blocks with the most key tiles are dispatched first, so the launch ends on the light ones
+  const int seq = bid.seq, head = bid.head, qb = CAUSAL ? p.n_qb - 1 - bid.qb : bid.qb;
   const int s0 = p.cu[seq];
   const int len = p.cu[seq + 1] - s0;
   if (qb * QB >= len) return;
@@ -105,40 +145,84 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
   constexpr float LOG2E = 1.4426950408889634f;
   const float c_exp = (RM == RM_POW2) ? p.scale * LOG2E : LOG2E;   // p = exp2(s * c_exp - m * c_exp)
 
-  // register staging of the NEXT tile (issued before the current tile's math, written to LDS after it)
+  // register staging of the NEXT tile (issued before the current tile's math, written to LDS after it).
+  // Addresses are a wave-uniform tile base (scalar registers) plus a per-lane 32-bit offset computed once; only a
+  // tile that straddles the sequence end takes the per-row clamped form.
   u32x4 kreg[C::LOADS], vreg[C::LOADS];
+  constexpr int ROWS_PER_LOAD = 256 / C::CHUNKS;
+  const int st_row = tid / C::CHUNKS, st_ch = tid % C::CHUNKS;
+  const unsigned k_lane_off = (unsigned)(st_row * (int)p.ldk + st_ch * 8) * 2u;
+  const unsigned v_lane_off = (unsigned)(st_row * (int)p.ldv + st_ch * 8) * 2u;
+  const char* const k_seq = (const char*)(Kg + (long)s0 * p.ldk);   // wave-uniform bases; offsets within a sequence fit 32 bits
+  const char* const v_seq = (const char*)(Vg + (long)s0 * p.ldv);
   auto load_tile = [&](int kt) {
+    unsigned ko[C::LOADS], vo[C::LOADS];
+    if (kt * KB + KB <= len) {
+#pragma unroll
+      for (int c = 0; c < C::LOADS; ++c) {
+        const unsigned r = (unsigned)(kt * KB + c * ROWS_PER_LOAD);   // wave-uniform
+        ko[c] = k_lane_off + r * (unsigned)p.ldk * 2u;
+        vo[c] = v_lane_off + r * (unsigned)p.ldv * 2u;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C::LOADS; ++c) {
+        int kr = kt * KB + st_row + c * ROWS_PER_LOAD;
+        kr = kr < len ? kr : len - 1;
+        ko[c] = (unsigned)(kr * (int)p.ldk + st_ch * 8) * 2u;
+        vo[c] = (unsigned)(kr * (int)p.ldv + st_ch * 8) * 2u;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < C::LOADS; ++c) {
-      const int idx = tid + c * 256;
-      const int row = idx / C::CHUNKS, ch = idx % C::CHUNKS;
-      int kr = kt * KB + row;
-      kr = kr < len ? kr : len - 1;
-      kreg[c] = *(const u32x4*)(Kg + (long)(s0 + kr) * p.ldk + ch * 8);
-      vreg[c] = *(const u32x4*)(Vg + (long)(s0 + kr) * p.ldv + ch * 8);
+      kreg[c] = *(const u32x4*)(k_seq + ko[c]);
+      vreg[c] = *(const u32x4*)(v_seq + vo[c]);
     }
   };
+  char* const k_st = Ks + st_row * C::KP + st_ch * 16;
+  char* const v_st = Vs + st_row * C::VP + st_ch * 16;
   auto store_tile = [&]() {
 #pragma unroll
     for (int c = 0; c < C::LOADS; ++c) {
-      const int idx = tid + c * 256;
-      const int row = idx / C::CHUNKS, ch = idx % C::CHUNKS;
-      *(u32x4*)(Ks + row * C::KP + ch * 16) = kreg[c];
-      *(u32x4*)(Vs + row * C::VP + ch * 16) = vreg[c];
+      *(u32x4*)(k_st + c * ROWS_PER_LOAD * C::KP) = kreg[c];
+      *(u32x4*)(v_st + c * ROWS_PER_LOAD * C::VP) = vreg[c];
     }
   };
 
-  load_tile(0);
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    __syncthreads();  // previous tile fully consumed
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < n_tiles) load_tile(kt + 1);  // in flight during this tile's MFMA / softmax work
+  // A q-block with at most 32 queries (the ragged end of a sequence: 1025 = 8 * 128 + 1 in the vision tower) is run by
+  // wave 0 alone: the other three waves leave at once and free their SIMD slots, wave 0 stages K / V by itself (no
+  // prefetch, no barriers: one wave's LDS operations execute in order) - the block then costs one wave slot instead of four.
+  // (D = 64 only: at D = 128 the second loop costs registers the main path does not have)
+  const bool solo = D == 64 && len - qb * QB <= 32;   // workgroup-uniform
+  if (solo && wave > 0) return;
+  auto stage_solo = [&](int kt) {
+#pragma unroll
+    for (int c0 = 0; c0 < KB * C::CHUNKS / 64; c0 += 2) {
+      u32x4 a[2], b[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int idx = lane + (c0 + c) * 64;
+        const int row = idx / C::CHUNKS, ch = idx % C::CHUNKS;
+        int kr = kt * KB + row;
+        kr = kr < len ? kr : len - 1;
+        a[c] = *(const u32x4*)(k_seq + (unsigned)(kr * (int)p.ldk + ch * 8) * 2u);
+        b[c] = *(const u32x4*)(v_seq + (unsigned)(kr * (int)p.ldv + ch * 8) * 2u);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int idx = lane + (c0 + c) * 64;
+        const int row = idx / C::CHUNKS, ch = idx % C::CHUNKS;
+        *(u32x4*)(Ks + row * C::KP + ch * 16) = a[c];
+        *(u32x4*)(Vs + row * C::VP + ch * 16) = b[c];
+      }
+    }
+  };
 
+  auto tile_math = [&](int kt) {
     const int k0 = kt * KB;
-    if (CAUSAL && k0 > q0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
-    if (q0 >= len) continue;               // wave-uniform: this wave has no query (ragged last q-block, e.g. 1025 = 8*128 + 1):
-                                           // it only helps staging K/V and keeps the barriers balanced
+    if (CAUSAL && k0 > q0 + 31) return;    // wave-uniform: tile entirely above this wave's diagonal
+    if (q0 >= len) return;                 // wave-uniform: this wave has no query (ragged last q-block): it only helps
+                                           // staging K/V and keeps the barriers balanced
 
     // ---- S^T = K Q^T : two 32-key sub-tiles
     f32x16 sacc[2];
@@ -171,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[t2][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, round_score<RM>(mx, p.scale));
     if (__any(m_new > m_run)) {            // exact: rescale only when some query's running max moved
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
@@ -205,9 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
       pf[t2][0] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
       pf[t2][1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
     }
-    float psum = psum2[0] + psum2[1];
-    psum += __shfl_xor(psum, 32, 64);
-    l_run += psum;
+    l_run += xhalf_sum(psum2[0] + psum2[1]);
 
     // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads.
     // element j of the fragment <-> key 32*t2 + 16*s2 + 8*(j>>2) + 4*hi + (j&3)
@@ -231,6 +313,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
           }
       }
     }
+  };
+
+  if (solo) {
+    for (int kt = 0; kt < n_tiles; ++kt) {
+      stage_solo(kt);
+      tile_math(kt);
+    }
+  } else {
+    load_tile(0);
+    for (int kt = 0; kt < n_tiles; ++kt) {
+      __syncthreads();  // previous tile fully consumed
+      store_tile();
+      __syncthreads();
+      if (kt + 1 < n_tiles) load_tile(kt + 1);  // in flight during this tile's MFMA / softmax work
+      tile_math(kt);
+    }
   }
 
   // ---- epilogue: O[query][d] = O^T / l ; lane = query, register r <-> d = 32*dt + (r&3) + 8*(r>>2) + 4*hi
@@ -248,233 +346,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------ software-pipelined form
-// Same math, different schedule: the QK^T MFMAs of tile t+1 are issued BEFORE the softmax of tile t, so the matrix pipe
-// works under the VALU-heavy softmax of the same wave (two score tiles live in registers), K and V are double-buffered
-// in LDS with K running one tile ahead of V, and there is ONE barrier per tile:
-//   iteration t:  issue global loads K(t+2), V(t+1) -> registers
-//                 S_next = K(t+1) Q^T           (LDS K slot (t+1)&1, written during iteration t-1)
-//                 softmax(S_cur) -> P, rescale  (VALU, overlaps the MFMAs above)
-//                 O^T += V(t)^T P^T             (LDS V slot t&1, written during iteration t-1)
-//                 registers -> LDS: K(t+2) into K slot t&1 (K(t) was last read in iteration t-1),
-//                                   V(t+1) into V slot (t+1)&1 (V(t-1) was last read in iteration t-1)
-//                 barrier
-template <int D, bool CAUSAL, int RM>
-__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(AttnArgs p) {
-  using C = Cfg<D>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * (C::K_BYTES + C::V_BYTES)];
-  char* Kbuf[2] = {smem, smem + C::K_BYTES};
-  char* Vbuf[2] = {smem + 2 * C::K_BYTES, smem + 2 * C::K_BYTES + C::V_BYTES};
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int seq = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
-  const int s0 = p.cu[seq];
-  const int len = p.cu[seq + 1] - s0;
-  if (qb * QB >= len) return;
-  const int kvh = head / p.kv_group;
-  const int q0 = qb * QB + wave * 32;
-  const int qi = q0 + l31;
-  const int qrow = s0 + (qi < len ? qi : len - 1);
-  const bool wave_on = q0 < len;
-
-  bf16x8 qf[D / 16];
-  {
-    const u16* qp = p.Q + (long)qrow * p.ldq + (long)head * p.qhs + 8 * hi;
-#pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-  f32x16 oacc[D / 32];
-#pragma unroll
-  for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int kv_end = CAUSAL ? min(len, (qb + 1) * QB) : len;
-  const int n_tiles = (kv_end + KB - 1) / KB;
-  const u16* Kg = p.K + (long)kvh * p.khs;
-  const u16* Vg = p.V + (long)kvh * p.vhs;
-  constexpr float LOG2E = 1.4426950408889634f;
-  const float c_exp = (RM == RM_POW2) ? p.scale * LOG2E : LOG2E;
-
-  u32x4 kreg[C::LOADS], vreg[C::LOADS];
-  auto load_k = [&](int kt) {
-#pragma unroll
-    for (int c = 0; c < C::LOADS; ++c) {
-      const int idx = tid + c * 256;
-      int kr = kt * KB + idx / C::CHUNKS;
-      kr = kr < len ? kr : len - 1;
-      kreg[c] = *(const u32x4*)(Kg + (long)(s0 + kr) * p.ldk + (idx % C::CHUNKS) * 8);
-    }
-  };
-  auto load_v = [&](int kt) {
-#pragma unroll
-    for (int c = 0; c < C::LOADS; ++c) {
-      const int idx = tid + c * 256;
-      int kr = kt * KB + idx / C::CHUNKS;
-      kr = kr < len ? kr : len - 1;
-      vreg[c] = *(const u32x4*)(Vg + (long)(s0 + kr) * p.ldv + (idx % C::CHUNKS) * 8);
-    }
-  };
-  auto store_k = [&](char* Ks) {
-#pragma unroll
-    for (int c = 0; c < C::LOADS; ++c) {
-      const int idx = tid + c * 256;
-      *(u32x4*)(Ks + (idx / C::CHUNKS) * C::KP + (idx % C::CHUNKS) * 16) = kreg[c];
-    }
-  };
-  auto store_v = [&](char* Vs) {
-#pragma unroll
-    for (int c = 0; c < C::LOADS; ++c) {
-      const int idx = tid + c * 256;
-      *(u32x4*)(Vs + (idx / C::CHUNKS) * C::VP + (idx % C::CHUNKS) * 16) = vreg[c];
-    }
-  };
-  auto qk = [&](const char* Ks, f32x16 (&sacc)[2]) {
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[t2][r] = 0.f;
-      const char* kp = Ks + (t2 * 32 + l31) * C::KP + hi * 16;
-#pragma unroll
-      for (int ks = 0; ks < D / 16; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(kp + ks * 32);
-        sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t2], 0, 0, 0);
-      }
-    }
-  };
-  // softmax of one score tile + PV with the matching V tile
-  auto softmax_pv = [&](f32x16 (&sacc)[2], const char* Vs, int k0) {
-    const bool need_mask = (k0 + KB > len) || (CAUSAL && (k0 + KB - 1 > q0));
-    if (need_mask) {
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = k0 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= len || (CAUSAL && key > qi)) sacc[t2][r] = -INFINITY;
-        }
-    }
-    float mx = sacc[0][0];
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[t2][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, round_score<RM>(mx, p.scale));
-    if (__any(m_new > m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-      m_run = m_new;
-    }
-    const f32x2 c2 = {c_exp, c_exp};
-    const f32x2 nmb2 = {-m_run * c_exp, -m_run * c_exp};
-    f32x2 psum2 = {0.f, 0.f};
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      unsigned pw[8];
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 a2 = {sacc[t2][r], sacc[t2][r + 1]};
-        f32x2 sr = round_pair(a2);
-        if constexpr (RM == RM_MUL) sr = round_pair(a2 * f32x2{p.scale, p.scale});
-        if constexpr (RM == RM_DIV) sr = round_pair(sr * f32x2{p.scale, p.scale});
-        const f32x2 e2 = sr * c2 + nmb2;
-        const f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
-        psum2 += pv;
-        pw[r >> 1] = pack_pair(pv);
-      }
-      pf[t2][0] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
-      pf[t2][1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
-    }
-    float psum = psum2[0] + psum2[1];
-    psum += __shfl_xor(psum, 32, 64);
-    l_run += psum;
-    const int g16 = (lane >> 4) & 1, li = lane & 15;
-    const int trow = li >> 2, tcol = 4 * (li & 3);
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int kbase = t2 * 32 + s2 * 16 + 4 * hi + trow;
-          const char* vp = Vs + kbase * C::VP + (dt * 32 + g16 * 16 + tcol) * 2;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
-          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * C::VP));
-          s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf[t2][s2], oacc[dt], 0, 0, 0);
-        }
-  };
-  auto tile_on = [&](int t) { return wave_on && t < n_tiles && !(CAUSAL && t * KB > q0 + 31); };
-
-  // ---- prologue: K(0), V(0), K(1) resident; S(0) computed
-  load_k(0);
-  load_v(0);
-  store_k(Kbuf[0]);
-  store_v(Vbuf[0]);
-  if (n_tiles > 1) {
-    load_k(1);
-    store_k(Kbuf[1]);
-  }
-  __syncthreads();
-  f32x16 sA[2], sB[2];
-  if (tile_on(0)) qk(Kbuf[0], sA);
-
-  // two tiles per trip so the score registers are addressed statically (sA <-> even tiles, sB <-> odd tiles)
-  for (int t = 0; t < n_tiles; t += 2) {
-    // ---------------- even tile t: scores in sA
-    if (t + 2 < n_tiles) load_k(t + 2);
-    if (t + 1 < n_tiles) load_v(t + 1);
-    if (tile_on(t + 1)) qk(Kbuf[1], sB);
-    if (tile_on(t)) softmax_pv(sA, Vbuf[0], t * KB);
-    if (t + 2 < n_tiles) store_k(Kbuf[0]);
-    if (t + 1 < n_tiles) store_v(Vbuf[1]);
-    __syncthreads();
-    if (t + 1 >= n_tiles) break;
-    // ---------------- odd tile t+1: scores in sB
-    if (t + 3 < n_tiles) load_k(t + 3);
-    if (t + 2 < n_tiles) load_v(t + 2);
-    if (tile_on(t + 2)) qk(Kbuf[0], sA);
-    if (tile_on(t + 1)) softmax_pv(sB, Vbuf[1], (t + 1) * KB);
-    if (t + 3 < n_tiles) store_k(Kbuf[1]);
-    if (t + 2 < n_tiles) store_v(Vbuf[0]);
-    __syncthreads();
-  }
-
-  if (qi < len) {
-    const float inv = 1.0f / l_run;
-    u16* op = p.O + (long)(s0 + qi) * p.ldo + (long)head * p.ohs;
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 v = {pack2bf(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
-                   pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv)};
-        *(u32x2*)(op + dt * 32 + 8 * g + 4 * hi) = v;
-      }
-  }
-}
-
-int g_attn_variant = 0;  // 0 = attn_kernel, 1 = attn_pipe_kernel (A/B in one process)
+// Schedules that were built, verified against the same tests and removed because they were not faster (DESIGN.md,
+// "Attention: what was measured"): two staggered wave groups per workgroup (one group issues MFMAs while its SIMD partner
+// runs the softmax, one s_barrier per segment) and a one-wave software pipeline (PV of tile t-1 and QK of tile t+1
+// interleaved instruction by instruction with the softmax of tile t).  On this part the softmax's vector work and the
+// MFMAs of a SIMD take close to the SUM of their times in every arrangement tried (tools/micro/coissue*.hip), so the
+// levers that paid were the ones that remove work or traffic: XCD-aware placement, leaner staging addresses, scalar
+// control flow, heaviest-first causal order, the one-wave ragged block.
 
 template <int D, bool CAUSAL>
-int launch(const AttnArgs& a, int n_seqs, int max_seqlen, hipStream_t s) {
-  dim3 grid((max_seqlen + QB - 1) / QB, a.n_heads, n_seqs);
+int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
   int e;
   const bool pow2 = a.round_mode == 0 && frexpf(a.scale, &e) == 0.5f;
-  if (g_attn_variant == 1) {
-    if (a.round_mode == 1) hipLaunchKernelGGL((attn_pipe_kernel<D, CAUSAL, RM_DIV>), grid, dim3(256), 0, s, a);
-    else if (pow2) hipLaunchKernelGGL((attn_pipe_kernel<D, CAUSAL, RM_POW2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_pipe_kernel<D, CAUSAL, RM_MUL>), grid, dim3(256), 0, s, a);
-    return mjv_check_launch("attention");
-  }
+  a.n_seqs = n_seqs;
+  a.n_qb = (max_seqlen + QB - 1) / QB;
+  const int total = a.n_qb * a.n_heads * n_seqs;
+  const dim3 grid(8 * ((total + 7) / 8));
   if (a.round_mode == 1) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV>), grid, dim3(256), 0, s, a);
   else if (pow2) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_POW2>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_MUL>), grid, dim3(256), 0, s, a);
@@ -484,11 +371,10 @@ int launch(const AttnArgs& a, int n_seqs, int max_seqlen, hipStream_t s) {
 }  // namespace
 
 extern "C" int mjv_attention_set_variant(int32_t v) {
-  if (v != 0 && v != 1) {
-    mjv_set_error("attention_set_variant: %d not in {0,1}", v);
+  if (v != 0) {   // kept in the ABI for A/B experiments; one schedule is built in at present
+    mjv_set_error("attention_set_variant: %d not in {0}", v);
     return MJV_E_ARG;
   }
-  g_attn_variant = v;
   return MJV_OK;
 }
 

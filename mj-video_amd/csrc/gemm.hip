@@ -57,6 +57,7 @@ struct GemmArgs {
   int out_group, out_pad;
   const int* out_rows;
   int tiles_m, tiles_n;
+  int gm;        // group-M of the tile order
   int nt_store;  // streaming stores for the output (host heuristic)
   int m_base;  // absolute index of row 0 of A (tail launches): output / residual rows are computed from m_base + m
 };
@@ -133,7 +134,7 @@ MJV_DEV void tile_of_vblock(const GemmArgs& p, const int nwg, const int b, int& 
   // tiles an XCD runs concurrently then form a GM x (32/GM) patch that shares GM activation panels and 32/GM weight
   // panels through that XCD's 4 MiB L2 (row-major order shares 1 + 32 panels: the whole weight matrix was re-fetched
   // over the fabric once per m-tile row - rocprofv3 FETCH_SIZE 4.7 GB per w1|w3 launch for 139 MB of operands).
-  constexpr int GM = 8;
+  const int GM = p.gm;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
   const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
   const int per_group = GM * p.tiles_n;
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
 int g_num_cus = 256;
+int g_gm = 8;
 int g_variant = 0;  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
 
 template <int EPI>
@@ -567,6 +569,10 @@ int launch(GemmArgs a, hipStream_t s, bool big) {
 }  // namespace
 
 extern "C" int mjv_gemm_set_tile(int32_t tile) {
+  if (tile >= 2000 && tile < 2100) {  // 2000 + gm: group-M of the tile order (tuning experiments)
+    g_gm = tile - 2000 > 0 ? tile - 2000 : 1;
+    return MJV_OK;
+  }
   if (tile >= 1000 && tile < 1010) {  // 1000 + v: keep the automatic tile choice, switch the 256-kernel variant
     g_variant = tile - 1000;
     g_force_tile = 0;
@@ -602,6 +608,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.out_rows = d->out_rows;
   a.tiles_m = a.tiles_n = 0;
   a.m_base = 0;
+  a.gm = g_gm;
   a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;
   const bool big = g_force_tile ? g_force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;

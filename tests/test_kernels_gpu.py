@@ -224,9 +224,9 @@ def test_patchify_cls_embed(cuda):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.fixture(params=[0, 1])
+@pytest.fixture(params=[0])
 def attn_variant(request, cuda):
-    """both attention schedules (plain / software-pipelined) on every attention test"""
+    """attention schedule selector (one schedule is built in at present; the hook stays for A/B experiments)"""
     from mj_video_amd import ops
     ops.attention_set_variant(request.param)
     yield request.param

@@ -26,11 +26,18 @@ def run(name, n_seq, L, H, G, D, causal, mode):
     print(f"{name:12s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF/s", flush=True)
 
 
-for rnd in range(3):
-    for v in (0, 1):
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+variants = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+for rnd in range(rounds):
+    for v in variants:
         ops.attention_set_variant(v)
         print("variant", v, end="  ")
         run("vit_d64", 64, 1025, 16, 1, 64, False, 0)
         print("variant", v, end="  ")
         run("llm_d128", 8, 2186, 16, 2, 128, True, 1)
+        if len(sys.argv) > 4:
+            print("variant", v, end="  "); run("d64_L1024", 64, 1024, 16, 1, 64, False, 0)
+            print("variant", v, end="  "); run("d128_L2048", 8, 2048, 16, 2, 128, False, 1)
+            print("variant", v, end="  "); run("d128c_L2048", 8, 2048, 16, 2, 128, True, 1)
+            print("variant", v, end="  "); run("d128c_L8192", 2, 8192, 16, 2, 128, True, 1)
 ops.attention_set_variant(0)
