@@ -175,6 +175,42 @@ def test_state_dict_layout_and_param_count():
         InternVLChatRewardModeling.from_config(bad)
 
 
+def test_checkpoint_directory_ingestion_and_setup_order(tmp_path):
+    """``InternVLChatRewardModeling(name, config)`` builds the base model from a local checkpoint
+    directory (config.json + sharded *.safetensors, the layout ``InternVLChatModel.from_pretrained`` reads in
+    moe_reward.py:142), then the harness order of eval_genai_mjvideo.py:73-116 works: load_state_dict(strict=True) of the
+    full reward checkpoint -> pad_token_id -> .to(bf16) -> img_context_token_id -> eval()."""
+    from safetensors.torch import save_file
+    cfg = make_cfg("tiny", 56)
+    cfg.save_pretrained(str(tmp_path))
+    sd = synth.synth_state_dict(cfg, seed=3, lm_head=True, dtype=torch.float32)
+    base = {k[len("model."):]: v.contiguous() for k, v in sd.items() if k.startswith("model.")}
+    keys = sorted(base)
+    half = len(keys) // 2
+    save_file({k: base[k] for k in keys[:half]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: base[k] for k in keys[half:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    re_cfg = C.InternVLChatRewardModelingConfig.from_pretrained(str(tmp_path), **{
+        k: getattr(cfg, k) for k in ("num_objectives", "num_aspects", "aspect2criteria", "gating_temperature",
+                                     "gating_hidden_dim", "gating_n_hidden")})
+    model = InternVLChatRewardModeling(str(tmp_path), re_cfg)
+    got = model.state_dict()
+    for k, v in base.items():
+        assert torch.equal(got["model." + k], v), k
+    # full reward checkpoint on top, strict, then the reference's set-up order
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.config.pad_token_id = 2
+    model = model.to(torch.bfloat16)
+    model.model.img_context_token_id = 92546
+    model.eval()
+    assert model.model.dtype == torch.bfloat16 and model.regression_layer.weight.dtype == torch.bfloat16
+    assert torch.equal(model.state_dict()["regression_layer.weight"], sd["regression_layer.weight"].to(torch.bfloat16))
+    # a shard with a key the model does not have is refused (strict), like the reference's load
+    save_file({"vision_model.bogus": torch.zeros(1)}, str(tmp_path / "model-00003-of-00002.safetensors"))
+    with pytest.raises(RuntimeError, match="bogus"):
+        InternVLChatRewardModeling(str(tmp_path), re_cfg)
+
+
 def test_model_refuses_cpu_and_non_bf16():
     cfg = make_cfg("tiny", 56)
     model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16)
