@@ -190,6 +190,8 @@ int mjv_resize_normalize_u8(const uint8_t* frames, int32_t n_frames, int32_t hei
  * for the roofline line (kernel average launch duration measured on the launch stream).
  * ------------------------------------------------------------------------------------------- */
 int mjv_prof_enable(int32_t on);
+/* record only launches with this tag (NULL or "" = every tag): lets a timed region carry events for one kernel only */
+int mjv_prof_filter(const char* tag);
 int mjv_prof_reset(void);
 int mjv_prof_collect(void);
 /* number of distinct tags seen; tag i: name, launches, total ms, total algorithmic flops, total algorithmic bytes */

@@ -72,6 +72,7 @@ SYMBOLS = {
     "mjv_resize_normalize_u8": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _I32, _I32,
                                            _I32, C.POINTER(C.c_float), C.POINTER(C.c_float), _VP]),
     "mjv_prof_enable": (C.c_int, [_I32]),
+    "mjv_prof_filter": (C.c_int, [C.c_char_p]),
     "mjv_prof_reset": (C.c_int, []),
     "mjv_prof_collect": (C.c_int, []),
     "mjv_prof_count": (C.c_int, []),

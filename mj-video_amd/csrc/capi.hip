@@ -20,6 +20,7 @@ struct ProfRec {
 };
 std::mutex g_mu;
 bool g_prof_on = false;
+std::string g_prof_only;  // when non-empty only this tag is recorded
 std::vector<ProfTag> g_tags;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -55,6 +56,7 @@ int mjv_check_launch(const char* what) {
 MjvProfScope::MjvProfScope(const char* tag, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_prof_only.empty() && g_prof_only != tag) return;
   int t = -1;
   for (size_t i = 0; i < g_tags.size(); ++i)
     if (g_tags[i].name == tag) { t = (int)i; break; }
@@ -90,6 +92,12 @@ const char* mjv_arch(void) { return "gfx950"; }
 int mjv_prof_enable(int32_t on) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_prof_on = on != 0;
+  return MJV_OK;
+}
+
+int mjv_prof_filter(const char* tag) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_prof_only = tag ? tag : "";
   return MJV_OK;
 }
 

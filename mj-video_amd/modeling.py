@@ -321,7 +321,9 @@ class InternVLChatRewardModeling(nn.Module):
         self._ws_tag = "g0"
         self._host_cache = None
         self._streams: List[torch.cuda.Stream] = []
-        self.n_streams = 2  # sample groups scored concurrently on separate HIP streams (1 = single stream)
+        # sample groups scored concurrently on separate HIP streams.  1 = everything on the caller's stream (default);
+        # 2-3 overlap one group's GEMM tail rounds with the other group's kernels: +1-2 % at twice the workspace
+        self.n_streams = 1
         self.debug_probes: Optional[Dict[str, torch.Tensor]] = None  # tests set {} to capture per-layer states
 
     # -- construction helpers -------------------------------------------------------------------

@@ -158,6 +158,11 @@ def prof_enable(on: bool) -> None:
     check(load_library().mjv_prof_enable(int(on)), "mjv_prof_enable")
 
 
+def prof_filter(tag: Optional[str]) -> None:
+    """Record only launches tagged ``tag`` (None: every kernel)."""
+    check(load_library().mjv_prof_filter(tag.encode() if tag else None), "mjv_prof_filter")
+
+
 def prof_reset() -> None:
     check(load_library().mjv_prof_reset(), "mjv_prof_reset")
 
