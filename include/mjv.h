@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MJV_ABI_VERSION 1
+#define MJV_ABI_VERSION 2
 
 enum {
   MJV_OK = 0,
@@ -74,11 +74,18 @@ typedef struct mjv_gemm_desc {
                                        + m % out_group   (skip the CLS slot of every tile)               */
   const int32_t* out_rows;          /* optional explicit output row per m (splice into <IMG_CONTEXT> rows,
                                        modeling_internvl_chat.py:176-179); overrides out_group            */
+  void* workspace;                  /* optional scratch (device, 16-B aligned) private to this stream while the call is in
+                                       flight; lets under-filled launches split K (fp32 partial tiles, summed in a fixed
+                                       order: results stay deterministic).  NULL: never split.  mjv_gemm_workspace_bytes() */
+  int64_t workspace_bytes;
 } mjv_gemm_desc;
+
+/* a workspace of this size is enough for every problem shape (512 partial 128x128 fp32 tiles) */
+int64_t mjv_gemm_workspace_bytes(void);
 
 int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);
 /* tile selection: 0 = automatic (256x256 8-wave kernel for M >= 512 and N >= 256, else 128x128), 128 or 256 force
- * one kernel (used by the parity tests to cover both on every shape). */
+ * one kernel (used by the parity tests to cover both on every shape); 4000 / 4001 switch split-K off / on. */
 int mjv_gemm_set_tile(int32_t tile);
 
 /* ---------------------------------------------------------------------------------------------

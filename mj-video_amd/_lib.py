@@ -22,12 +22,16 @@ class MjvLibraryError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2  # MJV_ABI_VERSION of include/mjv.h
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("epilogue", C.c_int32), ("bias", C.c_void_p), ("scale", C.c_void_p), ("res", C.c_void_p),
                 ("ldr", C.c_int64), ("res_mod", C.c_int32), ("res_off", C.c_int32), ("out_group", C.c_int32),
-                ("out_pad", C.c_int32), ("out_rows", C.c_void_p)]
+                ("out_pad", C.c_int32), ("out_rows", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64)]
 
 
 class AttnDesc(C.Structure):
@@ -59,6 +63,7 @@ SYMBOLS = {
     "mjv_last_error": (C.c_char_p, []),
     "mjv_arch": (C.c_char_p, []),
     "mjv_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _VP]),
+    "mjv_gemm_workspace_bytes": (C.c_int64, []),
     "mjv_gemm_set_tile": (C.c_int, [_I32]),
     "mjv_attention_bf16": (C.c_int, [C.POINTER(AttnDesc), _VP]),
     "mjv_attention_set_variant": (C.c_int, [_I32]),
@@ -117,8 +122,8 @@ def load_library():
             except AttributeError as e:
                 raise MjvLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype, fn.argtypes = res, args
-        if lib.mjv_abi_version() != 1:
-            raise MjvLibraryError(f"ABI version mismatch: library {lib.mjv_abi_version()} != binding 1")
+        if lib.mjv_abi_version() != ABI_VERSION:
+            raise MjvLibraryError(f"ABI version mismatch: library {lib.mjv_abi_version()} != binding {ABI_VERSION}")
         _lib = lib
         return lib
 

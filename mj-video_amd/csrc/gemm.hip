@@ -60,6 +60,8 @@ struct GemmArgs {
   int gm;        // group-M of the tile order
   int nt_store;  // streaming stores for the output (host heuristic)
   int m_base;  // absolute index of row 0 of A (tail launches): output / residual rows are computed from m_base + m
+  float* ws;   // split-K: fp32 partial tiles, [tile][slice][fragment][thread] float4 (the accumulators as they sit in registers)
+  int split;   // K slices per tile (1 = no split)
 };
 
 MJV_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
@@ -165,14 +167,19 @@ MJV_DEV void stage_tile(const u16* __restrict__ src, long ld, int row0, int max_
   }
 }
 
-template <int EPI>
+// SPLIT: the launch has split slices per tile (workgroup b = tile b / split, slice b % split); a slice covers a
+// contiguous share of the K-tiles and leaves its accumulators, as they sit in registers, in the fp32 workspace;
+// splitk_finish_kernel sums the slices in slice order (deterministic) and applies the epilogue.
+template <int EPI, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   int tm, tn;
-  tile_of_block(p, tm, tn);
+  const int tile_id = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x;
+  const int slice = SPLIT ? (int)blockIdx.x % p.split : 0;
+  tile_of_vblock(p, SPLIT ? (int)gridDim.x / p.split : (int)gridDim.x, tile_id, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4 acc[4][4];
@@ -181,9 +188,11 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
-  stage_tile(p.A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
-  stage_tile(p.W, p.ldw, n0, p.N - 1, 0, smem + TILE_BYTES, wave, lane);
+  const int nk_all = p.K / BK;
+  const int kt0 = SPLIT ? (int)((long)nk_all * slice / p.split) : 0;          // this slice's K-tiles [kt0, kt1)
+  const int nk = (SPLIT ? (int)((long)nk_all * (slice + 1) / p.split) : nk_all) - kt0;
+  stage_tile(p.A, p.lda, m0, p.M - 1, kt0 * BK, smem, wave, lane);
+  stage_tile(p.W, p.ldw, n0, p.N - 1, kt0 * BK, smem + TILE_BYTES, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -191,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
     char* cur = smem + (t & 1) * 2 * TILE_BYTES;
     char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
     if (t + 1 < nk) {
-      stage_tile(p.A, p.lda, m0, p.M - 1, (t + 1) * BK, nxt, wave, lane);
-      stage_tile(p.W, p.ldw, n0, p.N - 1, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+      stage_tile(p.A, p.lda, m0, p.M - 1, (kt0 + t + 1) * BK, nxt, wave, lane);
+      stage_tile(p.W, p.ldw, n0, p.N - 1, (kt0 + t + 1) * BK, nxt + TILE_BYTES, wave, lane);
     }
     const char* As = cur;
     const char* Ws = cur + TILE_BYTES;
@@ -220,6 +229,62 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
     __syncthreads();
   }
 
+  if constexpr (SPLIT) {
+    f32x4* img = (f32x4*)p.ws + ((long)tile_id * p.split + slice) * (16 * 256) + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) img[(i * 4 + j) * 256] = acc[i][j];
+    return;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mrel = m0 + wm * 64 + i * 16 + l15;
+    if (mrel >= p.M) continue;
+    const int m = p.m_base + mrel;
+    const long orow = out_row_of(p, m);
+    if constexpr (EPI == MJV_EPI_SILU_MUL) {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+        if (n >= p.N) continue;
+        store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+        if (n >= p.N) continue;
+        store_frag<EPI>(p, acc[i][j], m, orow, n);
+      }
+    }
+  }
+}
+
+// Second half of a split-K launch: one thread per (tile, thread of the GEMM workgroup); sums the slices' register images
+// in slice order and runs the same per-fragment epilogue code as the unsplit kernel.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int tm, tn;
+  tile_of_vblock(p, gridDim.x, blockIdx.x, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const f32x4* img = (const f32x4*)p.ws + (long)blockIdx.x * p.split * (16 * 256) + tid;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = img[(i * 4 + j) * 256];
+  for (int sl = 1; sl < p.split; ++sl) {
+    const f32x4* im2 = img + (long)sl * (16 * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += im2[(i * 4 + j) * 256];
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int mrel = m0 + wm * 64 + i * 16 + l15;
@@ -537,13 +602,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
 int g_num_cus = 256;
 int g_gm = 8;
+int g_split_k = 1;  // 1 = split-K for under-filled 128-tile launches when the caller gives a workspace (tile codes 4001 / 4000)
 int g_variant = 0;  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
 
 template <int EPI>
 int launch(GemmArgs a, hipStream_t s, bool big) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
@@ -561,14 +628,26 @@ int launch(GemmArgs a, hipStream_t s, bool big) {
   } else {
     a.tiles_m = (a.M + 127) / 128;
     a.tiles_n = (a.N + 127) / 128;
-    hipLaunchKernelGGL(t128::gemm128_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), t128::LDS_BYTES, s, a);
+    const int tiles = a.tiles_m * a.tiles_n;
+    if (a.split > 1) {
+      hipLaunchKernelGGL((t128::gemm128_kernel<EPI, true>), dim3(tiles * a.split), dim3(256), t128::LDS_BYTES, s, a);
+      hipLaunchKernelGGL(t128::splitk_finish_kernel<EPI>, dim3(tiles), dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((t128::gemm128_kernel<EPI, false>), dim3(tiles), dim3(256), t128::LDS_BYTES, s, a);
+    }
   }
   return mjv_check_launch("gemm_bf16");
 }
 
 }  // namespace
 
+extern "C" int64_t mjv_gemm_workspace_bytes(void) { return 512L * 65536L; }
+
 extern "C" int mjv_gemm_set_tile(int32_t tile) {
+  if (tile == 4000 || tile == 4001) {  // split-K of under-filled 128-tile launches off / on (A/B measurements)
+    g_split_k = tile - 4000;
+    return MJV_OK;
+  }
   if (tile >= 2000 && tile < 2100) {  // 2000 + gm: group-M of the tile order (tuning experiments)
     g_gm = tile - 2000 > 0 ? tile - 2000 : 1;
     return MJV_OK;
@@ -608,6 +687,8 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.out_rows = d->out_rows;
   a.tiles_m = a.tiles_n = 0;
   a.m_base = 0;
+  a.ws = nullptr;
+  a.split = 1;
   a.gm = g_gm;
   a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;
   const bool big = g_force_tile ? g_force_tile == 256 : (d->M >= 512 && d->N >= 256);
@@ -638,7 +719,25 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
     return MJV_E_ARG;
   }
   // one profiler scope per kernel launch, named like the kernel rocprofv3 reports (t256::gemm256_kernel<EPI> / t128::...)
+  // A 128-tile launch with fewer workgroups than the chip holds (the peeled tail rows, the batch-sized head GEMMs) is
+  // bound by each CU's L2->LDS fill rate (about 45 GB/s for one workgroup): its time is the launch's operand traffic
+  // divided by the CUs it occupies.  Splitting K over more workgroups engages the idle CUs; the slices' fp32
+  // accumulators go through the caller's workspace and a second, fully parallel launch sums them in slice order.
+  auto plan_split = [&](GemmArgs& g) {
+    if (!g_split_k || !d->workspace) return;
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128), nk = g.K / 64;
+    // measured (tools/gemm_bench.py, MJV_BENCH_TAILS=1): the second launch costs about 5 us, so K = 1024 / 2048 tails lose
+    // 1-5 us while K = 4096 / 8192 tails gain 12 / 25 us (45 -> 33, 89 -> 64)
+    if (tiles >= 2 * g_num_cus || nk < 64) return;
+    int sp = (2 * g_num_cus) / tiles;
+    if (sp > 8) sp = 8;
+    if (sp > nk / 4) sp = nk / 4;
+    if (sp < 2 || (long)tiles * sp * 65536L > d->workspace_bytes) return;
+    g.split = sp;
+    g.ws = (float*)d->workspace;
+  };
   auto run = [&](GemmArgs g, bool use_big) -> int {
+    if (!use_big) plan_split(g);
     const double frac = (double)g.M / (double)d->M;
     MjvProfScope ps(use_big ? tags256[d->epilogue] : tags128[d->epilogue], s, flops * frac, bytes * frac);
     switch (d->epilogue) {

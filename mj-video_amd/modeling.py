@@ -609,6 +609,8 @@ class InternVLChatRewardModeling(nn.Module):
         """Scores samples [lo, lo+B) of the batch on the CURRENT stream with its own workspace ``tag``."""
         dev = pixel_values.device
         self._ws_tag = tag
+        # split-K scratch of this group's GEMMs (per group = per stream: two streams never share one)
+        ops.set_gemm_workspace(self._buf("gemm_ws", 1, ops.gemm_workspace_bytes(), dev, dtype=torch.uint8))
         info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])  # host arrays (see forward)
         B, total = info["B"], info["total"]
         lc = self.config.llm_config

@@ -34,6 +34,22 @@ def _row_stride(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
+_GEMM_WS: Optional[torch.Tensor] = None
+
+
+def gemm_workspace_bytes() -> int:
+    return int(load_library().mjv_gemm_workspace_bytes())
+
+
+def set_gemm_workspace(ws: Optional[torch.Tensor]) -> None:
+    """Scratch buffer handed to every following ``gemm`` call issued from this thread's launches (uint8/any dtype, on the
+    GPU, private to the stream the calls go to while they are in flight).  None: GEMMs never split K."""
+    global _GEMM_WS
+    if ws is not None:
+        assert ws.is_cuda and ws.is_contiguous() and ws.data_ptr() % 16 == 0
+    _GEMM_WS = ws
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_BIAS,
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, res_mod: int = 0, res_off: int = 0, out_group: int = 0,
@@ -55,6 +71,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     if out_rows is not None:
         assert out_rows.dtype == torch.int32 and out_rows.is_cuda
     d.out_rows = _p(out_rows)
+    if _GEMM_WS is not None and _GEMM_WS.device == a.device:
+        d.workspace, d.workspace_bytes = _GEMM_WS.data_ptr(), _GEMM_WS.numel() * _GEMM_WS.element_size()
     check(lib.mjv_gemm_bf16(C.byref(d), _stream()), "mjv_gemm_bf16")
     return out
 

@@ -311,6 +311,61 @@ def test_attention_exact_selection(cuda, attn_variant):
     assert torch.equal(out.cpu()[:, :D], exp) and torch.equal(out.cpu()[:, D:], exp)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1104, 2048, 8192, "scale_res"), (64, 1024, 4096, "scale_res"), (64, 3072, 4096, "bias"),
+                                       (80, 1024, 4096, "silu"), (8, 1024, 8192, "relu"), (300, 136, 4160, "bias")])
+def test_gemm_split_k_matches_unsplit(cuda, M, N, K, epi):
+    """under-filled 128-tile launches (peeled tail rows, batch-sized head GEMMs) split K through the caller's workspace when
+    one is given: operands in {-1,0,1} keep every partial sum an exactly representable integer, so the split result must
+    equal the unsplit one and the fp32 reference bit for bit, for every epilogue the finishing kernel runs"""
+    from mj_video_amd import ops
+    g = torch.Generator().manual_seed(13)
+    a = torch.randint(-1, 2, (M, K), generator=g).float().to(BF).to(cuda)
+    w = torch.randint(-1, 2, (N, K), generator=g).float().to(BF).to(cuda)
+    # thin out the operands so |sum| stays below 256 (exact in bf16) even at K = 8192
+    a = a * (torch.rand(M, K, generator=g) < 0.15).to(BF).to(cuda)
+    bias = torch.randint(-2, 3, (N,), generator=g).float().to(BF).to(cuda)
+    res = torch.randint(-8, 9, (M, N if epi != "silu" else N // 2), generator=g).float().to(BF).to(cuda)
+    kw = {"bias": dict(epilogue=ops.EPI_BIAS, bias=bias), "relu": dict(epilogue=ops.EPI_BIAS_RELU, bias=bias),
+          "scale_res": dict(epilogue=ops.EPI_SCALE_RES, bias=bias, res=res), "silu": dict(epilogue=ops.EPI_SILU_MUL)}[epi]
+    nout = N // 2 if epi == "silu" else N
+    outs = []
+    ws = torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=cuda)
+    try:
+        ops.gemm_set_tile(128)    # the shapes above reach the 128-tile kernel as peeled tails inside the model
+        for use_ws in (False, True):
+            ops.set_gemm_workspace(ws if use_ws else None)
+            ws.fill_(255)         # all-ones words are NaNs: a slice that was written is finite afterwards
+            out = torch.full((M, nout), 7.0, dtype=BF, device=cuda)
+            ops.gemm(a, w, out, **kw)
+            outs.append(out.clone())
+            touched = bool(torch.isfinite(ws[:65536].view(torch.float32)).all())
+            assert touched == use_ws, "split-K path taken when it should not be (or not taken when it should)"
+        ops.gemm_set_tile(4000)   # split-K switched off in the library: the workspace must be ignored
+        ws.fill_(255)
+        out = torch.full((M, nout), 7.0, dtype=BF, device=cuda)
+        ops.gemm(a, w, out, **kw)
+        outs.append(out.clone())
+        assert not bool(torch.isfinite(ws[:65536].view(torch.float32)).any())
+    finally:
+        ops.gemm_set_tile(4001)
+        ops.gemm_set_tile(0)
+        ops.set_gemm_workspace(None)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    lin = a.float() @ w.float().t()
+    if epi == "bias":
+        ref = (lin + bias.float()).to(BF)
+    elif epi == "relu":
+        ref = F.relu((lin + bias.float()).to(BF))
+    elif epi == "scale_res":
+        ref = (res.float() + (lin + bias.float()).to(BF).float()).to(BF)
+    else:
+        lin16 = lin.to(BF).view(M, N // 32, 2, 16)
+        ref = (F.silu(lin16[:, :, 0]) * lin16[:, :, 1]).reshape(M, N // 2)
+        assert_close_bf16(outs[1], ref, 3, frac_exact=0.95, atol=2e-3, what="split_k_silu")
+        return
+    assert torch.equal(outs[1], ref)
+
+
 def test_gemm_pipeline_race_screen(cuda):
     """the 256^2 kernel keeps LDS-DMA in flight across barriers: repeat an exact-integer problem many times on a
     busy chip (many tiles, deep K) and require every run bit-identical to the exact result"""

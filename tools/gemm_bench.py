@@ -8,6 +8,7 @@ import mj_video_amd
 from mj_video_amd import ops
 
 dev = torch.device("cuda:0")
+WS = None
 BF = torch.bfloat16
 
 
@@ -19,7 +20,12 @@ def bench(M, N, K, epi, tile, iters=20):
     bias = torch.randn(N, device=dev).to(BF) if epi not in (ops.EPI_SILU_MUL,) else None
     res = torch.randn(M, nout, device=dev).to(BF) if epi == ops.EPI_SCALE_RES else None
     scale = torch.randn(N, device=dev).to(BF) if epi == ops.EPI_SCALE_RES else None
-    if tile >= 2000:
+    if tile >= 5000:      # 5000 + tile: same tile choice with a split-K workspace
+        global WS
+        WS = WS if WS is not None else torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ops.set_gemm_workspace(WS)
+        ops.gemm_set_tile(tile - 5000)
+    elif tile >= 2000:
         ops.gemm_set_tile(1000); ops.gemm_set_tile(tile)
     else:
         ops.gemm_set_tile(tile)
@@ -33,7 +39,7 @@ def bench(M, N, K, epi, tile, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    ops.gemm_set_tile(2008); ops.gemm_set_tile(0)
+    ops.gemm_set_tile(2008); ops.gemm_set_tile(0); ops.set_gemm_workspace(None)
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
@@ -44,6 +50,12 @@ shapes = [("square8k", 8192, 8192, 8192, ops.EPI_BIAS), ("square4k", 4096, 4096,
           ("llm_wqkv", 17488, 4096, 2048, ops.EPI_BIAS), ("llm_wo", 17488, 2048, 2048, ops.EPI_SCALE_RES),
           ("llm_w13", 17488, 16384, 2048, ops.EPI_SILU_MUL), ("llm_w2", 17488, 2048, 8192, ops.EPI_SCALE_RES),
           ("llm_w2_16384", 16384, 2048, 8192, ops.EPI_SCALE_RES)]
+if os.environ.get("MJV_BENCH_TAILS"):   # the peeled tail problems of the model's GEMMs (single stream), as standalone launches
+    shapes = [("tail_vit_qkv", 64, 3072, 1024, ops.EPI_BIAS), ("tail_vit_proj", 64, 1024, 1024, ops.EPI_SCALE_RES),
+              ("tail_vit_fc1", 64, 4096, 1024, ops.EPI_BIAS_GELU), ("tail_vit_fc2", 64, 1024, 4096, ops.EPI_SCALE_RES),
+              ("tail_llm_wqkv", 1104, 4096, 2048, ops.EPI_BIAS), ("tail_llm_wo", 1104, 2048, 2048, ops.EPI_SCALE_RES),
+              ("tail_llm_w13", 80, 16384, 2048, ops.EPI_SILU_MUL), ("tail_llm_w2", 1104, 2048, 8192, ops.EPI_SCALE_RES),
+              ("main_llm_w2", 16384, 2048, 8192, ops.EPI_SCALE_RES), ("main_vit_fc2", 65536, 1024, 4096, ops.EPI_SCALE_RES)]
 tiles = [int(t) for t in sys.argv[1:]] or [256]
 ROUNDS = 3
 for name, M, N, K, epi in shapes:
