@@ -602,6 +602,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
 int g_num_cus = 256;
 int g_gm = 8;
+int g_split_max = 8;  // cap on the slices per tile (tile codes 4100 + cap, experiments)
 int g_split_k = 1;  // 1 = split-K for under-filled 128-tile launches when the caller gives a workspace (tile codes 4001 / 4000)
 int g_variant = 0;  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
 
@@ -644,6 +645,10 @@ int launch(GemmArgs a, hipStream_t s, bool big) {
 extern "C" int64_t mjv_gemm_workspace_bytes(void) { return 512L * 65536L; }
 
 extern "C" int mjv_gemm_set_tile(int32_t tile) {
+  if (tile > 4100 && tile <= 4108) {
+    g_split_max = tile - 4100;
+    return MJV_OK;
+  }
   if (tile == 4000 || tile == 4001) {  // split-K of under-filled 128-tile launches off / on (A/B measurements)
     g_split_k = tile - 4000;
     return MJV_OK;
@@ -730,7 +735,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
     // 1-5 us while K = 4096 / 8192 tails gain 12 / 25 us (45 -> 33, 89 -> 64)
     if (tiles >= 2 * g_num_cus || nk < 64) return;
     int sp = (2 * g_num_cus) / tiles;
-    if (sp > 8) sp = 8;
+    if (sp > g_split_max) sp = g_split_max;
     if (sp > nk / 4) sp = nk / 4;
     if (sp < 2 || (long)tiles * sp * 65536L > d->workspace_bytes) return;
     g.split = sp;

@@ -7,9 +7,11 @@ different fp32 accumulation order, i.e. it is another sample of that same noise 
 the same amount when only its CPU thread count changes: full_c1 video 0 scores +1.2804 with 6 threads and +1.2280
 with 4).  Every output field must therefore satisfy
     |hip - ref_bf16| <= TOL_FACTOR * noise_floor(field) + ATOL_FLOOR
-where noise_floor is max|ref_bf16 - ref_fp32| over the fixture set of that configuration; TOL_FACTOR = 3 because the
-difference of two noise samples is sqrt(2) larger than one and a maximum over 4-5 fixture cases under-estimates the
-maximum over all the elements compared.
+where noise_floor is max|ref_bf16 - ref_fp32| over every fixture of that model size that holds an fp32 run of the reference
+(pooled_noise_floor: a 2-video fixture alone says little about the spread - see its docstring for how far ONE re-associated
+fp32 sum moves a score); TOL_FACTOR = 3 because the difference of two noise samples is sqrt(2) larger than one and a
+maximum over a few fixture cases under-estimates the maximum over all the elements compared.  The statistical statements
+(rms deviation, preference agreement on decisive pairs, rank correlation) are made on the rank sets.
 """
 import numpy as np
 import pytest
@@ -25,6 +27,37 @@ ATOL_FLOOR = 2e-3
 def noise_floor(npz, prefixes, field):
     return max(float(np.abs(npz[f"{p}/{field}"] - npz[f"{p}/fp32/{field}"]).max()) for p in prefixes
                if f"{p}/fp32/{field}" in npz.files)
+
+
+_PACKED34 = {"score": slice(0, 1), "aspect_scores": slice(1, 6), "rewards": slice(6, 34)}
+
+
+def pooled_noise_floor(field):
+    """max |ref_bf16 - ref_fp32| of ``field`` over EVERY MJ-VIDEO-2B-dims fixture that holds an fp32 run of the reference
+    (full_c1: 4 videos, full_c2: 2, rank sets: 128 + 12 videos for score / aspect_scores / rewards).  A two-video fixture
+    under-estimates the reference's own spread badly: the path is chaotic at bf16 - re-associating the fp32 sums of 16 of
+    the 16 400 ViT rows of full_c2 (split-K 8 / 4 / 3 / 2 / off in the fc2 tail) moves video 1's score through
+    0.43 / 1.02 / 0.72 / 0.86 / 0.65 while the reference's bf16 run sits at 0.73 and its fp32 run at 0.63
+    (tools/c2_probe.py) - so the per-video bound uses the largest sample of that spread the fixtures offer."""
+    worst = 0.0
+    for tag in ("full_c1", "full_c2"):
+        try:
+            npz, meta = load_golden(tag)
+        except FileNotFoundError:
+            continue
+        pre = [f"v{v['video_idx']}" for v in meta["videos"] if f"v{v['video_idx']}/fp32/{field}" in npz.files]
+        if pre:
+            worst = max(worst, noise_floor(npz, pre, field))
+    if field in _PACKED34:
+        for tag in ("rankset_c1", "rankset_c2"):
+            try:
+                npz, _ = load_golden(tag)
+            except FileNotFoundError:
+                continue
+            b, f = npz["ref_bf16"][..., _PACKED34[field]], npz["ref_fp32"][..., _PACKED34[field]]
+            have = ~np.isnan(f[:, 0, 0])
+            worst = max(worst, float(np.abs(b[have] - f[have]).max()))
+    return worst
 
 
 def rel_l2(a, b):
@@ -104,7 +137,7 @@ def _full_case(cuda, tag, image_size):
             if f in ("hidden_state", "prompt_embedding"):
                 assert rel_l2(got, ref) < 0.03, (tag, p, f, rel_l2(got, ref))
                 continue
-            tol = TOL_FACTOR * noise_floor(npz, with_fp32, f) + ATOL_FLOOR
+            tol = TOL_FACTOR * max(noise_floor(npz, with_fp32, f), pooled_noise_floor(f)) + ATOL_FLOOR
             d = float(np.abs(got - ref).max())
             print(f"{tag} {p} {f}: max|d|={d:.3e} tol={tol:.3e}")
             assert d <= tol, f"{tag}:{p}:{f} max|d|={d:.4e} > tol {tol:.4e}"
@@ -176,7 +209,9 @@ def _rank_case(cuda, name, pairs_per_forward):
           f"|hip-fp32|: max={d32.max():.3e} rms={np.sqrt((d32 ** 2).mean()):.3e}")
     # (1) the HIP path is statistically no further from the reference than the reference is from its own fp32 run
     assert np.sqrt((d ** 2).mean()) <= 2.0 * noise_rms + ATOL_FLOOR
-    assert d.max() <= TOL_FACTOR * noise_max + ATOL_FLOOR
+    # the worst single video: 3 x the largest reference deviation seen, or 8 x its rms when only a few fp32 runs exist
+    # (the maximum of 12 samples says little about the maximum of 96; see pooled_noise_floor about the heavy tail)
+    assert d.max() <= max(TOL_FACTOR * noise_max, 8.0 * noise_rms) + ATOL_FLOOR
     # (2) pairwise preference on the decisive pairs of the fixed set: a sign can only flip when the margin is below the
     #     sum of the two videos' errors, so pairs with margin > 4 x max noise are the ones the metric is defined on
     margin = np.abs(ref[:, 0, 0] - ref[:, 1, 0])
@@ -188,7 +223,14 @@ def _rank_case(cuda, name, pairs_per_forward):
           f"reference bf16-vs-fp32 self-agreement on {int(have32.sum())} pairs={self_agree.mean():.4f}")
     assert decisive.sum() >= 0.5 * P, "synthetic set has too many near-ties to be meaningful"
     assert agree[decisive].mean() >= 0.999
-    assert agree.mean() >= 0.95
+    # all pairs, near-ties included: a pair flips when the two videos' deviations (each ~ sqrt(2) x the reference's noise,
+    # so 2 x noise_rms on the margin) exceed its margin; the agreement must not fall below what that noise model predicts
+    from scipy.stats import norm
+    p_flip = norm.cdf(-margin / (2.0 * noise_rms))
+    expected = 1.0 - p_flip.mean()
+    sigma = float(np.sqrt((p_flip * (1 - p_flip)).sum())) / P
+    print(f"all-pairs agreement {agree.mean():.4f}; predicted from the reference's own noise {expected:.4f} +- {sigma:.4f}")
+    assert agree.mean() >= expected - 3.0 * sigma
     # (3) good/bad flag (score > 0) away from zero, (4) rank correlation over all 2P scores
     good = (got[..., 0] > 0) == (ref[..., 0] > 0)
     far = np.abs(ref[..., 0]) > 2 * noise_max
