@@ -11,6 +11,9 @@ constexpr int MAX_IT = 8;         // 8 chunks of 512 elements -> rows up to 4096
 // nn.LayerNorm on a bf16 tensor: fp32 mean / biased variance, y = bf16((x - mean) * rstd * g + b).
 // gather_grid > 0: the logical input row is the concatenation of 4 rows of the ViT output (pixel shuffle,
 // modeling_internvl_chat.py:228-242): out token (tile, a2, b2) <- rows (2a2,2b2) (2a2,2b2+1) (2a2+1,2b2) (2a2+1,2b2+1).
+// IT = chunks of 512 elements a lane group covers (row width <= 512 * IT): the narrower instantiations keep fewer values
+// in registers, so more rows are in flight per CU.
+template <int IT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ y, long ldy,
                                                         const u16* __restrict__ gamma, const u16* __restrict__ beta,
                                                         int rows, int dim, float eps, int grid) {
@@ -30,10 +33,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
     src_base[2] = (tb + (2 * a2 + 1) * grid + 2 * b2) * ldx;
     src_base[3] = (tb + (2 * a2 + 1) * grid + 2 * b2 + 1) * ldx;
   }
-  float v[MAX_IT][8];
+  float v[IT][8];
   float sum = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) {
+  for (int it = 0; it < IT; ++it) {
     const int c = it * 512 + lane * 8;
     if (c < dim) {
       const u16* src;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
   const float mean = wave_sum(sum) / (float)dim;
   float sq = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) {
+  for (int it = 0; it < IT; ++it) {
     const int c = it * 512 + lane * 8;
     if (c < dim) {
 #pragma unroll
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
   const float var = wave_sum(sq) / (float)dim;
   const float rstd = rsqrtf(var + eps);
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) {
+  for (int it = 0; it < IT; ++it) {
     const int c = it * 512 + lane * 8;
     if (c < dim) {
       float g[8], b[8], o[8];
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
 
 // ------------------------------------------------------------------------------------------ RMSNorm
 // modeling_internlm2.py:138-143: h = bf16(x32 * rsqrt(mean(x32^2) + eps)); y = bf16(w * h)
+template <int IT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ y, long ldy,
                                                       const u16* __restrict__ w, const int* __restrict__ row_index,
                                                       int rows, int dim, float eps) {
@@ -86,10 +90,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* __restrict__ x,
   const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
   const long srow = row_index ? row_index[row] : row;
-  float v[MAX_IT][8];
+  float v[IT][8];
   float sq = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) {
+  for (int it = 0; it < IT; ++it) {
     const int c = it * 512 + lane * 8;
     if (c < dim) {
       unpack8(*(const u32x4*)(x + srow * ldx + c), v[it]);
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* __restrict__ x,
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)dim + eps);
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) {
+  for (int it = 0; it < IT; ++it) {
     const int c = it * 512 + lane * 8;
     if (c < dim) {
       float g[8], o[8];
@@ -196,8 +200,13 @@ extern "C" int mjv_layernorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, i
   if (gather_grid > 0) MJV_REQUIRE(gather_grid % 2 == 0 && dim % 32 == 0, "layernorm: gather needs an even grid");
   hipStream_t s = (hipStream_t)stream;
   MjvProfScope ps(gather_grid > 0 ? "layernorm_pixshuf" : "layernorm", s, 0, 4.0 * rows * (double)dim);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + WAVES - 1) / WAVES), dim3(256), 0, s, x, (long)ldx, y, (long)ldy, gamma,
-                     beta, rows, dim, eps, gather_grid);
+  const dim3 grid((rows + WAVES - 1) / WAVES);
+  if (dim <= 1024)
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, gamma, beta, rows, dim, eps, gather_grid);
+  else if (dim <= 2048)
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, gamma, beta, rows, dim, eps, gather_grid);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<MAX_IT>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, gamma, beta, rows, dim, eps, gather_grid);
   return mjv_check_launch("layernorm");
 }
 
@@ -208,8 +217,13 @@ extern "C" int mjv_rmsnorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int
   MJV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "rmsnorm: ld alignment");
   hipStream_t s = (hipStream_t)stream;
   MjvProfScope ps("rmsnorm", s, 0, 4.0 * rows * (double)dim);
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + WAVES - 1) / WAVES), dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w,
-                     row_index, rows, dim, eps);
+  const dim3 grid((rows + WAVES - 1) / WAVES);
+  if (dim <= 1024)
+    hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w, row_index, rows, dim, eps);
+  else if (dim <= 2048)
+    hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w, row_index, rows, dim, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<MAX_IT>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w, row_index, rows, dim, eps);
   return mjv_check_launch("rmsnorm");
 }
 
