@@ -77,6 +77,9 @@ def cpu_baseline(config, image_size, n_tiles, threads):
     return 0.5 / dt, dt
 
 
+METRIC = "video-pairs scored/sec, MJ-VIDEO-2B 8-frame bf16, 1/2/4/8 MI355X"   # BASELINE.json "metric", verbatim
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +184,7 @@ def main():
         total_pairs = args.pairs * world * args.steps
         value = total_pairs / elapsed
         line = {
-            "metric": "video-pairs scored/sec, MJ-VIDEO-2B 8-frame bf16",
+            "metric": METRIC,
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
