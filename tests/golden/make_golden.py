@@ -157,6 +157,9 @@ def gen_full(tag: str, S: int, n_videos: int, wseed: int, pixel_seed: int, n_til
               open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
 
 
+RESUME = False
+
+
 def gen_rankset(tag: str, S: int, pairs: int, wseed: int, pixel_seed: int, fp32_every: int, n_tiles: int = 8):
     """P pairs; both videos of pair p share caption seed 1000+p.  Stores the 34 numbers per video
     SURVEY.md §8(e) names (score, 5 aspect scores, 28 rewards) from the reference in bf16, and the
@@ -168,8 +171,14 @@ def gen_rankset(tag: str, S: int, pairs: int, wseed: int, pixel_seed: int, fp32_
     out = np.zeros((pairs, 2, 34), dtype=np.float32)
     out32 = np.full((pairs, 2, 34), np.nan, dtype=np.float32)
     path = os.path.join(HERE, f"{tag}.npz")
+    first = 0
+    if RESUME and os.path.isfile(path):   # extend an existing set (same seeds / thread count): keep what is there
+        old = np.load(path)
+        first = min(old["ref_bf16"].shape[0], pairs)
+        out[:first], out32[:first] = old["ref_bf16"][:first], old["ref_fp32"][:first]
+        print(f"[{tag}] resuming after {first} pairs", flush=True)
     t_start = time.time()
-    for p in range(pairs):
+    for p in range(first, pairs):
         ids = synth.synth_input_ids(n_img_tokens(cfg, n_tiles), caption_seed=1000 + p)
         mask = torch.ones_like(ids)
         for j in range(2):
@@ -185,7 +194,8 @@ def gen_rankset(tag: str, S: int, pairs: int, wseed: int, pixel_seed: int, fp32_
                 out32[p, j, 6:] = f["rewards"][0].numpy()
         print(f"[{tag}] pair {p}: {out[p, 0, 0]:+.5f} {out[p, 1, 0]:+.5f}  ({time.time() - t_start:.0f}s)", flush=True)
         if p % 8 == 7 or p == pairs - 1:
-            np.savez_compressed(path, ref_bf16=out[:p + 1], ref_fp32=out32[:p + 1])
+            np.savez_compressed(path + ".tmp.npz", ref_bf16=out[:p + 1], ref_fp32=out32[:p + 1])
+            os.replace(path + ".tmp.npz", path)   # atomic: a snapshot of the tree never sees a half-written fixture
             json.dump(dict(kind="2b", image_size=S, weight_seed=wseed, pixel_seed=pixel_seed, pairs=p + 1,
                            n_tiles=n_tiles, caption_seed_base=1000, fp32_every=fp32_every,
                            cpu_threads=torch.get_num_threads(),
@@ -198,8 +208,10 @@ if __name__ == "__main__":
     ap.add_argument("what", choices=["tiny", "full_c1", "full_c2", "rankset_c1", "rankset_c2"])
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--resume", action="store_true", help="rank sets: keep the pairs already in the fixture and append")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
+    RESUME = a.resume
     if a.what == "tiny":
         gen_tiny()
     elif a.what == "full_c1":

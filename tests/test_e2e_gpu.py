@@ -276,6 +276,29 @@ def test_streams_and_last_layer_trimming_are_invisible(cuda):
         assert torch.equal(getattr(one, f), getattr(full, f)), f
 
 
+def test_forward_is_deterministic_at_headline_shape(cuda):
+    """headline batch (8 videos x 8 tiles @448: M = 65 600 / 17 488 - every large GEMM peels tail rows, the long-K tails split
+    K, the ViT attention runs its one-wave ragged block): repeated forwards must agree bit for bit (split-K sums its slices
+    in a fixed order, no atomics anywhere), which also screens the kernels for races under a full-size load"""
+    from mj_video_amd import synth
+    cfg = make_cfg("2b", 448)
+    sd = synth.synth_state_dict(cfg, seed=0, lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
+        cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
+    model = build_hip_model(cfg, sd, cuda)
+    vids = [dict(video_idx=i, n_tiles=8, caption_seed=i) for i in range(8)]
+    px, ids, mask, _ = case_inputs(cfg, vids, 78, 448)
+    px, ids, mask = px.to(cuda), ids.to(cuda), mask.to(cuda)
+    ref = model.forward(px, ids, mask)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref.score).all()
+    for it in range(4):
+        got = model.forward(px, ids, mask)
+        torch.cuda.synchronize()
+        for f in FIELDS:
+            assert torch.equal(getattr(got, f), getattr(ref, f)), (it, f)
+
+
 def test_error_behaviour(cuda):
     """the reference's ValueErrors (moe_reward.py:57,218-219) and the build's loud failures"""
     from mj_video_amd import synth
