@@ -736,6 +736,14 @@ class InternVLChatRewardModeling(nn.Module):
         if pixel_values.shape[-1] % self.config.vision_config.patch_size == 0:
             self._pos_table(d, pixel_values.shape[-1] // self.config.vision_config.patch_size, dev)
         groups = self._split_batch(ids_h, pixel_values.shape[0], n_groups)
+        try:
+            self._run_groups(d, groups, pixel_values, ids_h, am_h, outs, dev)
+        finally:   # the split-K scratch is a process-wide setting of ops: do not leave it behind for other gemm callers
+            ops.set_gemm_workspace(None)
+        self.last_packed34 = outs.pop("packed34")
+        return CustomOutput(**outs)
+
+    def _run_groups(self, d, groups, pixel_values, ids_h, am_h, outs, dev):
         if len(groups) == 1:
             self._forward_group(d, "g0", pixel_values, ids_h, am_h, outs, 0, True)
         else:
@@ -755,5 +763,3 @@ class InternVLChatRewardModeling(nn.Module):
                     done = torch.cuda.Event()
                     done.record(st)
                 main.wait_event(done)
-        self.last_packed34 = outs.pop("packed34")
-        return CustomOutput(**outs)
