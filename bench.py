@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="sample groups scored concurrently on separate HIP streams (2-3 streams: +1-2 %% pairs/s, but the "
                          "per-kernel event durations then include time shared with the other stream's kernel)")
+    ap.add_argument("--gemm-code", type=int, action="append", default=[],
+                    help="A/B switches of the GEMM library (mjv_gemm_set_tile codes, e.g. 4000 = no split-K, 6000 = tails in "
+                         "their own launch); not for reported numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -117,6 +120,8 @@ def main():
     model.model.img_context_token_id = synth.IMG_CONTEXT_ID
     model.eval()
     model.n_streams = args.streams
+    for code in args.gemm_code:
+        ops.gemm_set_tile(code)
 
     n_videos = 2 * args.pairs
     per_tile = num_image_tokens_per_tile(cfg)
