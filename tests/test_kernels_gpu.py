@@ -437,3 +437,38 @@ def test_attention_long_context_c4(cuda, attn_variant):
         rel = (got - ref).norm() / ref.norm()
         assert rel.item() < 6e-3, (h, rel.item())
         assert (got - ref).abs().max().item() < 0.03
+
+
+# ------------------------------------------------------------------------------------------ event profiler
+def test_event_profiler_tags_and_filter(cuda):
+    """bench.py's roofline numbers come from the library's opt-in event profiler: every launch is tagged like the kernel
+    rocprofv3 reports, flops are the algorithmic 2MNK, and a filter restricts recording to one tag (the timed region
+    carries events for the dominant kernel only)"""
+    from mj_video_amd import ops
+    a, w = rnd(1024, 256, seed=1).to(cuda), rnd(512, 256, std=0.05, seed=2).to(cuda)
+    out = torch.empty(1024, 512, dtype=BF, device=cuda)
+    x, g, b = rnd(64, 256, seed=3).to(cuda), rnd(256, seed=4).to(cuda), rnd(256, seed=5).to(cuda)
+    y = torch.empty(64, 256, dtype=BF, device=cuda)
+    try:
+        ops.prof_filter(None)
+        ops.prof_reset()
+        ops.prof_enable(True)
+        for _ in range(3):
+            ops.gemm(a, w, out, ops.EPI_BIAS)
+        ops.layernorm(x, g, b, y, 1e-6)
+        ops.prof_enable(False)
+        res = ops.prof_results()
+        assert res["gemm256_bias"]["launches"] == 3 and res["layernorm"]["launches"] == 1
+        assert res["gemm256_bias"]["flops"] == 3 * 2.0 * 1024 * 512 * 256 and res["gemm256_bias"]["ms"] > 0
+        ops.prof_reset()
+        ops.prof_filter("layernorm")
+        ops.prof_enable(True)
+        ops.gemm(a, w, out, ops.EPI_BIAS)
+        ops.layernorm(x, g, b, y, 1e-6)
+        ops.prof_enable(False)
+        res = ops.prof_results()
+        assert set(res) == {"layernorm"} and res["layernorm"]["launches"] == 1
+    finally:
+        ops.prof_enable(False)
+        ops.prof_filter(None)
+        ops.prof_reset()
