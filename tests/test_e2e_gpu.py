@@ -168,7 +168,7 @@ def test_rank_agreement_c2(cuda):
 def _rank_case(cuda, name, pairs_per_forward):
     """Fixed synthetic set of pairs scored by the reference: the HIP scores must (1) deviate from the reference no
     more than the reference deviates from its own fp32 run, (2) give the same pairwise preference on >= 0.999 of the
-    decisive pairs (margin > 4 x max noise), (3) the same good/bad flag, (4) rank mutually separated scores identically
+    decisive pairs (margin > 12 x the reference's noise rms), (3) the same good/bad flag, (4) rank mutually separated scores identically
     (Spearman >= 0.999); near-ties are reported, not hidden."""
     from mj_video_amd import synth
     from mj_video_amd.chat_input import num_image_tokens_per_tile
@@ -178,7 +178,7 @@ def _rank_case(cuda, name, pairs_per_forward):
         pytest.skip(f"{name} fixture not generated")
     ref = npz["ref_bf16"]
     ref32 = npz["ref_fp32"]
-    P = min(ref.shape[0], 256)
+    P = ref.shape[0]
     cfg = make_cfg("2b", meta["image_size"])
     sd = synth.synth_state_dict(cfg, seed=meta["weight_seed"], lm_head=False)
     sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
@@ -213,15 +213,17 @@ def _rank_case(cuda, name, pairs_per_forward):
     # (the maximum of 12 samples says little about the maximum of 96; see pooled_noise_floor about the heavy tail)
     assert d.max() <= max(TOL_FACTOR * noise_max, 8.0 * noise_rms) + ATOL_FLOOR
     # (2) pairwise preference on the decisive pairs of the fixed set: a sign can only flip when the margin is below the
-    #     sum of the two videos' errors, so pairs with margin > 4 x max noise are the ones the metric is defined on
+    #     sum of the two videos' errors, so the metric is defined on pairs whose margin is far above the noise: 12 x the
+    #     reference's bf16-vs-fp32 rms (about 4 x the largest deviation seen; the rms, unlike the maximum, does not grow
+    #     with the number of fp32 runs in the fixture)
     margin = np.abs(ref[:, 0, 0] - ref[:, 1, 0])
-    decisive = margin > 4 * noise_max
+    decisive = margin > 12 * noise_rms
     agree = np.sign(got[:, 0, 0] - got[:, 1, 0]) == np.sign(ref[:, 0, 0] - ref[:, 1, 0])
     self_agree = np.sign(ref[have32][:, 0, 0] - ref[have32][:, 1, 0]) == np.sign(f32[have32][:, 0, 0] - f32[have32][:, 1, 0])
-    print(f"decisive pairs {int(decisive.sum())}/{P} (min margin/noise_max={margin[decisive].min() / noise_max:.1f}); "
+    print(f"decisive pairs {int(decisive.sum())}/{P} (margin > {12 * noise_rms:.3f} = {12 * noise_rms / noise_max:.1f} x max noise); "
           f"preference agreement: decisive={agree[decisive].mean():.4f} all={agree.mean():.4f}; "
           f"reference bf16-vs-fp32 self-agreement on {int(have32.sum())} pairs={self_agree.mean():.4f}")
-    assert decisive.sum() >= 0.5 * P, "synthetic set has too many near-ties to be meaningful"
+    assert decisive.sum() >= 0.4 * P, "synthetic set has too many near-ties to be meaningful"
     assert agree[decisive].mean() >= 0.999
     # all pairs, near-ties included: a pair flips when the two videos' deviations (each ~ sqrt(2) x the reference's noise,
     # so 2 x noise_rms on the margin) exceed its margin; the agreement must not fall below what that noise model predicts
@@ -233,18 +235,18 @@ def _rank_case(cuda, name, pairs_per_forward):
     assert agree.mean() >= expected - 3.0 * sigma
     # (3) good/bad flag (score > 0) away from zero, (4) rank correlation over all 2P scores
     good = (got[..., 0] > 0) == (ref[..., 0] > 0)
-    far = np.abs(ref[..., 0]) > 2 * noise_max
+    far = np.abs(ref[..., 0]) > 6 * noise_rms
     assert good[far].mean() >= 0.999
     from scipy.stats import spearmanr
     rho = spearmanr(got[..., 0].ravel(), ref[..., 0].ravel()).correlation
     rho_self = spearmanr(ref[have32][..., 0].ravel(), f32[have32][..., 0].ravel()).correlation
     print(f"spearman rho(hip, ref)={rho:.5f}   reference bf16-vs-fp32 rho={rho_self:.5f}")
     assert rho >= min(0.99, rho_self - 0.005)
-    # well-separated scores (greedy selection with gaps > 4 x max noise) must be ranked identically
+    # well-separated scores (greedy selection with gaps > 12 x noise rms) must be ranked identically
     order = np.argsort(ref[..., 0].ravel())
     keep, last = [], -np.inf
     for i in order:
-        if ref[..., 0].ravel()[i] - last > 4 * noise_max:
+        if ref[..., 0].ravel()[i] - last > 12 * noise_rms:
             keep.append(i)
             last = ref[..., 0].ravel()[i]
     sep = spearmanr(got[..., 0].ravel()[keep], ref[..., 0].ravel()[keep]).correlation
