@@ -217,7 +217,7 @@ if __name__ == "__main__":
     elif a.what == "full_c1":
         gen_full("full_c1", 224, n_videos=4, wseed=0, pixel_seed=200, check_oracle=4)
     elif a.what == "full_c2":
-        gen_full("full_c2", 448, n_videos=2, wseed=0, pixel_seed=300, check_oracle=2)
+        gen_full("full_c2", 448, n_videos=4, wseed=0, pixel_seed=300, check_oracle=2)
     elif a.what == "rankset_c1":
         gen_rankset("rankset_c1", 224, a.pairs, wseed=0, pixel_seed=400, fp32_every=4)
     elif a.what == "rankset_c2":

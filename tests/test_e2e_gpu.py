@@ -150,7 +150,7 @@ def test_full_c1_against_golden(cuda):
 
 
 def test_full_c2_against_golden(cuda):
-    """MJ-VIDEO-2B dims, 8 frames @448, N = 2186 (BASELINE.json configs[1] shape), 2 videos batched"""
+    """MJ-VIDEO-2B dims, 8 frames @448, N = 2186 (BASELINE.json configs[1] shape), 4 videos batched"""
     _full_case(cuda, "full_c2", 448)
 
 
