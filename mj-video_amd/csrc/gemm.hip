@@ -70,7 +70,9 @@ struct GemmArgs {
   int split;   // K slices per tile (1 = no split)
 };
 
-MJV_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+// x * rcp(1 + e^-x): v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division; the result is rounded to bf16 next, and
+// e^-x is a 1-2 ulp v_exp_f32 already, so the quotient's last fp32 bit carries no information the reference shares
+MJV_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
