@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
   // A q-block with at most 32 queries (the ragged end of a sequence: 1025 = 8 * 128 + 1 in the vision tower) is run by
   // wave 0 alone: the other three waves leave at once and free their SIMD slots, wave 0 stages K / V by itself (no
   // prefetch, no barriers: one wave's LDS operations execute in order) - the block then costs one wave slot instead of four.
-  // (D = 64 only: at D = 128 the second loop costs registers the main path does not have)
+  // (D = 64 only: at D = 128 the second loop costs registers - 256 + spills for the causal kernel - and measures slower)
   const bool solo = D == 64 && len - qb * QB <= 32;   // workgroup-uniform
   if (solo && wave > 0) return;
   auto stage_solo = [&](int kt) {
@@ -224,17 +224,42 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
     if (q0 >= len) return;                 // wave-uniform: this wave has no query (ragged last q-block): it only helps
                                            // staging K/V and keeps the barriers balanced
 
-    // ---- S^T = K Q^T : two 32-key sub-tiles
+    // ---- S^T = K Q^T : two 32-key sub-tiles.  D = 128: the K fragments are read three MFMAs ahead of their use (the compiler's
+    // own order hoists all 16 reads, 64 registers); D = 64 keeps the compiler's order - the ring costs it 19 spilled
+    // registers under the 128-register cap that four waves per SIMD need, and measures slower
     f32x16 sacc[2];
+    if constexpr (D == 128) {
+      constexpr int N_QK = 2 * (D / 16), AHEAD = 3, RING = 4;
+      const char* kp = Ks + l31 * C::KP + hi * 16;
+      bf16x8 kr[RING];
+      auto read_k = [&](int i, bf16x8& f) {   // i = (D / 16) * t2 + ks
+        f = *(const bf16x8*)(kp + (i / (D / 16)) * 32 * C::KP + (i % (D / 16)) * 32);
+      };
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
+      for (int i = 0; i < AHEAD; ++i) read_k(i, kr[i % RING]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[t2][r] = 0.f;
-      const char* kp = Ks + (t2 * 32 + l31) * C::KP + hi * 16;
+      for (int i = 0; i < N_QK; ++i) {
+        if (i + AHEAD < N_QK) read_k(i + AHEAD, kr[(i + AHEAD) % RING]);
+        const int t2 = i / (D / 16), ks = i % (D / 16);
+        if (ks == 0) {
 #pragma unroll
-      for (int ks = 0; ks < D / 16; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(kp + ks * 32);
-        sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t2], 0, 0, 0);
+          for (int r = 0; r < 16; ++r) sacc[t2][r] = 0.f;
+        }
+        sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i % RING], qf[ks], sacc[t2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t2][r] = 0.f;
+        const char* kp = Ks + (t2 * 32 + l31) * C::KP + hi * 16;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(kp + ks * 32);
+          sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t2], 0, 0, 0);
+        }
       }
     }
 
@@ -293,24 +318,31 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 
     // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads.
     // element j of the fragment <-> key 32*t2 + 16*s2 + 8*(j>>2) + 4*hi + (j&3)
+    // The reads run AHEAD of the MFMA that consumes them (a ring of fragments in the registers the score tile just left):
+    // left to itself the compiler issues {2 reads, wait, MFMA} eight times and every MFMA eats a full LDS latency.
     {
       const int g16 = (lane >> 4) & 1;     // which 16-column block of the 32-wide d tile
       const int li = lane & 15;
       const int trow = li >> 2, tcol = 4 * (li & 3);
+      const char* vbase = Vs + (4 * hi + trow) * C::VP + (g16 * 16 + tcol) * 2;
+      constexpr int N_PV = 4 * (D / 32), AHEAD = 3, RING = 4;
+      bf16x8 fr[RING];
+      auto read_v = [&](int i, bf16x8& f) {   // i = 4 * dt + 2 * t2 + s2
+        const char* vp = vbase + (i & 3) * 16 * C::VP + (i >> 2) * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+        const s16x4 hi4 =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * C::VP));
+        const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        f = __builtin_bit_cast(bf16x8, v8);
+      };
 #pragma unroll
-      for (int dt = 0; dt < D / 32; ++dt) {
+      for (int i = 0; i < AHEAD; ++i) read_v(i, fr[i % RING]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int kbase = t2 * 32 + s2 * 16 + 4 * hi + trow;
-            const char* vp = Vs + kbase * C::VP + (dt * 32 + g16 * 16 + tcol) * 2;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
-            const s16x4 hi4 =
-                __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * C::VP));
-            s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf[t2][s2], oacc[dt], 0, 0, 0);
-          }
+      for (int i = 0; i < N_PV; ++i) {
+        if (i + AHEAD < N_PV) read_v(i + AHEAD, fr[(i + AHEAD) % RING]);
+        oacc[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % RING], pf[(i >> 1) & 1][i & 1], oacc[i >> 2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
