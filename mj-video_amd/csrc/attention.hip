@@ -218,11 +218,16 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
     }
   };
 
-  auto tile_math = [&](int kt) {
+  // prefetch = true: this wave's share of the NEXT tile's global loads is issued after the QK^T MFMAs (the staging
+  // registers are then free while the K fragments are read, and still have the softmax and the PV product to land)
+  auto tile_math = [&](int kt, bool prefetch) {
     const int k0 = kt * KB;
-    if (CAUSAL && k0 > q0 + 31) return;    // wave-uniform: tile entirely above this wave's diagonal
-    if (q0 >= len) return;                 // wave-uniform: this wave has no query (ragged last q-block): it only helps
-                                           // staging K/V and keeps the barriers balanced
+    // wave-uniform: tile entirely above this wave's diagonal, or a wave without a query (ragged last q-block): it only
+    // helps staging K/V and keeps the barriers balanced
+    if ((CAUSAL && k0 > q0 + 31) || q0 >= len) {
+      if (prefetch) load_tile(kt + 1);
+      return;
+    }
 
     // ---- S^T = K Q^T : two 32-key sub-tiles.  D = 128: the K fragments are read three MFMAs ahead of their use (the compiler's
     // own order hoists all 16 reads, 64 registers); D = 64 keeps the compiler's order - the ring costs it 19 spilled
@@ -262,6 +267,8 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
         }
       }
     }
+
+    if (prefetch) load_tile(kt + 1);
 
     // ---- masks only where a tile straddles the sequence end or the causal diagonal (wave-uniform test)
     const bool need_mask = (k0 + KB > len) || (CAUSAL && (k0 + KB - 1 > q0));
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
   if (solo) {
     for (int kt = 0; kt < n_tiles; ++kt) {
       stage_solo(kt);
-      tile_math(kt);
+      tile_math(kt, false);
     }
   } else {
     load_tile(0);
@@ -358,8 +365,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
       __syncthreads();  // previous tile fully consumed
       store_tile();
       __syncthreads();
-      if (kt + 1 < n_tiles) load_tile(kt + 1);  // in flight during this tile's MFMA / softmax work
-      tile_math(kt);
+      tile_math(kt, kt + 1 < n_tiles);
     }
   }
 
