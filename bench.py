@@ -4,6 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Called WITHOUT a launcher and with --gpus N > 1 it starts the N ranks itself (a child `python -m torch.distributed.run`
+on 127.0.0.1, started before this process touches a GPU; the parent only waits and passes rank 0's JSON line through).
+
 One "step" = one pass of the reward-scoring hot path over one batch of synthetic pairs per GPU
 (BASELINE.json configs[1]: 4 pairs = 8 videos x 8 tiles, N = 2186 tokens per video), inputs already
 resident in HBM, random-init weights of the exact MJ-VIDEO-2B architecture.  Pairs are sharded
@@ -14,7 +17,9 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   "roofline":     dominant kernel's algorithmic TFLOP/s (HIP events on the launch stream, recorded inside the
                   timed region by the library's opt-in profiler) against the 2.5 PFLOP/s dense bf16 MFMA peak,
   "cpu_baseline": the oracle (CPU restatement of the reference forward, bf16, LM head included as the
-                  reference executes it) timed on this host on ONE video of the same workload (N=1 only).
+                  reference executes it) timed on this host: 1 warm-up + 2 timed forwards of ONE video, for the C2
+                  (headline) and the C1 (224^2) shapes, CPU model / physical cores / threads stated (N=1 only),
+  "latency":      one video per forward (the reference's real call pattern, eval_genai_mjvideo.py:140-141), ms.
 """
 import argparse
 import json
@@ -64,17 +69,43 @@ def random_init_on_device(model, config, device, seed):
             p.zero_()
 
 
-def cpu_baseline(config, image_size, n_tiles, threads):
-    """Oracle forward of one video of the workload on the host CPU (checker code, timed only as a baseline)."""
+def host_cpu_info():
+    """(model name, physical cores, logical cpus) of this host from /proc/cpuinfo."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("processor"):
+                logical += 1
+            elif ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or (os.cpu_count() or 1)), (logical or (os.cpu_count() or 1))
+
+
+def cpu_baseline(image_size, n_tiles, threads, iters=2):
+    """Oracle forward of one video of the workload on the host CPU (checker code, timed only as a baseline):
+    1 warm-up forward, then ``iters`` timed ones."""
     from oracle import ref_cpu
     torch.set_num_threads(threads)
+    config = C.InternVLChatRewardModelingConfig(**C.mjvideo_2b_config_dict(image_size), **C.mjvideo_head_kwargs())
     sd = synth.synth_state_dict(config, seed=0)
     px = synth.synth_pixel_values(300, 0, n_tiles, image_size)
     ids = synth.synth_input_ids(num_image_tokens_per_tile(config) * n_tiles, 0)
-    t0 = time.time()
-    ref_cpu.reward_forward(sd, config, px, ids, torch.ones_like(ids), synth.IMG_CONTEXT_ID, synth.PAD_ID, lm_head=True)
-    dt = time.time() - t0
-    return 0.5 / dt, dt
+    times = []
+    for it in range(1 + iters):
+        t0 = time.time()
+        ref_cpu.reward_forward(sd, config, px, ids, torch.ones_like(ids), synth.IMG_CONTEXT_ID, synth.PAD_ID, lm_head=True)
+        if it:
+            times.append(time.time() - t0)
+    dt = sum(times) / len(times)
+    return 0.5 / dt, dt, int(ids.shape[1])
 
 
 METRIC = "video-pairs scored/sec, MJ-VIDEO-2B 8-frame bf16, 1/2/4/8 MI355X"   # BASELINE.json "metric", verbatim
@@ -98,12 +129,24 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # No launcher: start the N ranks as fresh children (one process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE
+        # this process has made any GPU call - it never does: it waits, passes the children's output (rank 0's JSON line)
+        # through and exits with their code.  Never re-exec a process that has initialised the GPU.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs: the scoring path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -137,7 +180,9 @@ def main():
     gathered = torch.empty(world * n_videos, 34, dtype=torch.float32, device=dev) if world > 1 else None
 
     def step():
-        model.forward(px, ids, mask)
+        # fresh id / mask tensors every step, as every real batch brings: the forward pays its device->host copy of the
+        # ids (the model caches the host copy only for the SAME unmodified tensor objects)
+        model.forward(px, ids.clone(), mask.clone())
         block = model.last_packed34
         if world > 1:
             dist.all_gather_into_tensor(gathered, block)
@@ -181,8 +226,12 @@ def main():
     if not torch.isfinite(out).all():
         raise SystemExit("non-finite scores")
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ranks_seen = 1
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        who = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(who, torch.tensor([rank], dtype=torch.int64, device=dev))   # RCCL all-gather
+        ranks_seen = int(torch.unique(who).numel())
     elapsed = float(t.item())
 
     if rank == 0:
@@ -192,11 +241,12 @@ def main():
             "metric": METRIC,
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
             "config": {"workload": f"MJ-VIDEO-2B, batch={args.pairs} pairs per GPU, {F} frames @{S}^2 max_num=1, "
                                    f"N={seq_len} tokens/video, random-init weights, inputs resident in HBM",
                        "pairs_per_gpu_per_step": args.pairs, "global_pairs_per_step": args.pairs * world,
                        "hip_streams_per_gpu": args.streams,
+                       "ids": "fresh id / mask tensors every step (one device->host copy of the ids per forward)",
                        "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
             "frac_of_mfma_roofline": round(value * ALGO_TFLOP_PER_PAIR / (MFMA_BF16_PEAK_TFLOPS * world), 4)
             if (S, F) == (448, 8) else None,
@@ -205,9 +255,9 @@ def main():
             res = ops.prof_results()
 
             traffic = {}
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if (S, F, args.pairs) == (448, 8, 4) and os.path.isfile(tpath):
-                traffic = json.load(open(tpath)).get("per_launch_bytes", {})
+            tpaths = sorted(p_ for p_ in os.listdir(os.path.join(ROOT, "profiles")) if p_.endswith("_pmc_traffic.json"))
+            if (S, F, args.pairs) == (448, 8, 4) and tpaths:   # the latest round's committed PMC passes
+                traffic = json.load(open(os.path.join(ROOT, "profiles", tpaths[-1]))).get("per_launch_bytes", {})
 
             def roofline(res, steps, share_from=None):
                 share_from = share_from or res
@@ -217,7 +267,7 @@ def main():
                 return {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4),
                         # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same workload
-                        # (profiles/r01_pmc_traffic.json; a PMC run cannot be nested inside this process)
+                        # (profiles/rNN_pmc_traffic.json; a PMC run cannot be nested inside this process)
                         "traffic": traffic.get(name),
                         "algorithmic_bytes_per_launch": round(r["bytes"] / max(r["launches"], 1)),
                         "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(r["launches"], 1), 4),
@@ -255,14 +305,41 @@ def main():
                 line["roofline_isolated"]["ms_per_step_single_stream"] = round(iso_ms, 3)
                 line["kernels_isolated"] = table(iso, 2)
                 model.n_streams = args.streams
+        if world == 1:
+            # the reference's real call pattern: ONE video per forward (eval_genai_mjvideo.py:140-141), fresh ids each time
+            px1, ids1, mask1 = px[:F].contiguous(), ids[:1].contiguous(), mask[:1].contiguous()
+            for _ in range(2):
+                model.forward(px1, ids1.clone(), mask1.clone())
+            torch.cuda.synchronize()
+            n_lat = 10
+            t1 = time.perf_counter()
+            for _ in range(n_lat):
+                model.forward(px1, ids1.clone(), mask1.clone())
+            torch.cuda.synchronize()
+            lat_ms = 1e3 * (time.perf_counter() - t1) / n_lat
+            t1 = time.perf_counter()
+            model.forward(px1, ids1.clone(), mask1.clone())
+            host_ms = 1e3 * (time.perf_counter() - t1)   # enqueue time of one forward (the GPU is still running it)
+            torch.cuda.synchronize()
+            line["latency"] = {"one_video_per_forward_ms": round(lat_ms, 3), "host_enqueue_ms": round(host_ms, 3),
+                               "pairs_per_s_at_batch_1_video": round(0.5e3 / lat_ms, 3),
+                               "note": "back-to-back single-video forwards, not part of `value`"}
         if world == 1 and not args.no_cpu_baseline:
             # oneDNN bf16 GEMMs stop scaling (and oversubscribe NUMA domains) far below a 256-thread host: cap at 32
-            threads = min(os.cpu_count() or 1, 32)
+            cpu_model, phys, logical = host_cpu_info()
+            threads = min(phys, 32)
             try:
-                v, dt = cpu_baseline(cfg, S, F, threads)
+                v, dt, n2 = cpu_baseline(S, F, threads)
                 line["cpu_baseline"] = {"value": round(v, 5), "unit": "pairs/s", "cores": threads, "kind": "port",
-                                        "sample": f"1 video ({F} tiles @{S}^2, N={seq_len}) = half a pair, one oracle forward "
-                                                  f"in bf16 incl. the reference's unused LM-head GEMM, {dt:.1f}s, no warm-up"}
+                                        "sample": f"1 video ({F} tiles @{S}^2, N={n2}) = half a pair per oracle forward in bf16 "
+                                                  f"incl. the reference's unused LM-head GEMM; 1 warm-up + 2 timed forwards, "
+                                                  f"{dt:.1f}s each",
+                                        "cpu_model": cpu_model, "physical_cores": phys, "logical_cpus": logical,
+                                        "threads": threads}
+                if (S, F) == (448, 8):
+                    v1, dt1, n1 = cpu_baseline(224, 8, threads)
+                    line["cpu_baseline"]["c1_224"] = {"value": round(v1, 5), "unit": "pairs/s",
+                                                      "sample": f"1 video (8 tiles @224^2, N={n1}), 1 warm-up + 2 timed, {dt1:.1f}s each"}
             except Exception as e:  # the baseline is informational; never lose the GPU number over it
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(line), flush=True)

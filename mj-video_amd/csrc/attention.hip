@@ -426,6 +426,10 @@ extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
                   d->o_head_stride % 4 == 0, "attention: head stride alignment");
   MJV_REQUIRE(((uintptr_t)d->Q | (uintptr_t)d->K | (uintptr_t)d->V) % 16 == 0 && (uintptr_t)d->O % 8 == 0,
               "attention: misaligned pointer");
+  // K / V staging offsets inside one sequence are 32-bit byte offsets (row * ld * 2)
+  MJV_REQUIRE((double)d->max_seqlen * (double)(d->ldk > d->ldv ? d->ldk : d->ldv) * 2.0 < 2147483648.0,
+              "attention: max_seqlen * max(ldk, ldv) * 2 = %.0f bytes does not fit the 32-bit staging offsets",
+              (double)d->max_seqlen * (double)(d->ldk > d->ldv ? d->ldk : d->ldv) * 2.0);
   AttnArgs a;
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;

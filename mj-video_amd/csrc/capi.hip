@@ -1,6 +1,7 @@
 // Host-side glue of libmjv_hip.so: error reporting, launch checking and the opt-in event profiler.
 #include "mjv_common.h"
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -51,6 +52,19 @@ int mjv_check_launch(const char* what) {
     return MJV_E_LAUNCH;
   }
   return MJV_OK;
+}
+
+int mjv_device_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int n = cus[dev & 63].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 
 MjvProfScope::MjvProfScope(const char* tag, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {

@@ -29,6 +29,7 @@
 // Epilogues reproduce the reference's bf16 op boundaries (one rounding per torch op).
 #include "mjv_common.h"
 #include "gelu_table.h"
+#include <atomic>
 
 namespace {
 
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 }  // namespace t256
 
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
-int g_num_cus = 256;
+thread_local int g_num_cus = 256;   // CUs of the device of the call in flight (mjv_device_cus), set in mjv_gemm_bf16
 int g_gm = 8;
 int g_split_max = 8;  // cap on the slices per tile (tile codes 4100 + cap, experiments)
 int g_split_k = 1;  // 1 = split-K for under-filled 128-tile launches when the caller gives a workspace (tile codes 4001 / 4000)
@@ -616,14 +617,18 @@ int g_variant = 0;  // experimental kernel variant (A/B in one process): tile co
 
 template <int EPI>
 int launch(GemmArgs a, hipStream_t s, bool big) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the dynamic-LDS limit is a per-device function attribute: set it once on every device this instantiation runs on
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
     (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
-    attr_done = true;
+    attr_done.fetch_or(bit, std::memory_order_release);   // racing first calls both set the attributes: idempotent
   }
   if (big) {
     a.tiles_m = (a.M + 255) / 256;
@@ -706,6 +711,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;
   const bool big = g_force_tile ? g_force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;
+  g_num_cus = mjv_device_cus();   // tail peeling and split-K plan against the CUs of THIS device (partitioned parts differ)
   const double flops = 2.0 * d->M * (double)d->N * d->K;
   const double bytes = 2.0 * ((double)d->M * d->K + (double)d->N * d->K + (double)d->M * d->N);
   // Wave quantisation: with one 256x256 workgroup per CU a launch runs in ceil(tiles / 256) rounds, and a last round

@@ -55,6 +55,7 @@ MJV_DEV float wave_max(float v) {
 // ---- host side -------------------------------------------------------------------------------
 void mjv_set_error(const char* fmt, ...);
 int mjv_check_launch(const char* what);
+int mjv_device_cus();   // multiProcessorCount of the current device (cached per device)
 
 // profiler hooks (capi.cpp)
 struct MjvProfScope {

@@ -251,20 +251,28 @@ class InternVLChatModel(nn.Module):
         return self.mlp1[1].weight.dtype
 
     @classmethod
-    def from_pretrained(cls, name_or_path, config: Optional[InternVLChatConfig] = None, **kwargs):
-        """Builds the model from ``config.json`` in a local directory and loads ``*.safetensors`` next to it
-        when present (no hub access exists here; the reference's HF call is modeling_internvl_chat.py / moe_reward.py:142)."""
+    def from_pretrained(cls, name_or_path, config: Optional[InternVLChatConfig] = None,
+                        allow_uninitialized: bool = False, **kwargs):
+        """Builds the model from ``config.json`` in a local directory and loads the ``*.safetensors`` next to it
+        (no hub access exists here; the reference's HF call is modeling_internvl_chat.py / moe_reward.py:142).
+        Like the reference, it either returns real base weights or fails: a path that is not a local directory, or
+        one without ``*.safetensors``, raises FileNotFoundError unless ``allow_uninitialized=True`` (the caller then
+        owns the ``torch.empty`` parameters and must ``load_state_dict`` a full checkpoint before scoring)."""
         if config is None:
             config = InternVLChatConfig.from_pretrained(name_or_path)
         model = cls(config)
+        files = []
         if isinstance(name_or_path, str) and os.path.isdir(name_or_path):
             files = sorted(f for f in os.listdir(name_or_path) if f.endswith(".safetensors"))
-            if files:
-                from safetensors.torch import load_file
-                sd = {}
-                for f in files:
-                    sd.update(load_file(os.path.join(name_or_path, f)))
-                model.load_state_dict(sd, strict=True)
+        if files:
+            from safetensors.torch import load_file
+            sd = {}
+            for f in files:
+                sd.update(load_file(os.path.join(name_or_path, f)))
+            model.load_state_dict(sd, strict=True)
+        elif not allow_uninitialized:
+            raise FileNotFoundError(f"no *.safetensors weights under {name_or_path!r}: the model would score with "
+                                    "uninitialised parameters (pass allow_uninitialized=True to build the skeleton only)")
         return model
 
 
@@ -472,6 +480,11 @@ class InternVLChatRewardModeling(nn.Module):
             lens = np.full(B, N, dtype=np.int64)
         if (lens <= 0).any():
             raise ValueError("empty sequence in the batch")
+        vocab = self.model.language_model.model.tok_embeddings.weight.shape[0]
+        valid = ids if am is None else ids[am]
+        if valid.size and (int(valid.min()) < 0 or int(valid.max()) >= vocab):   # nn.Embedding raises here too
+            raise IndexError(f"token id out of range [0, {vocab}): min {int(valid.min())}, max {int(valid.max())} "
+                             "(tokenizer / checkpoint mismatch?)")
         reward_rows, gating_rows, packed, positions, img_rows = [], [], [], [], []
         cu = [0]
         for b in range(B):
@@ -670,7 +683,7 @@ class InternVLChatRewardModeling(nn.Module):
         hd.aspect_scores = outs["aspect_scores"][lo:].data_ptr()
         hd.score = outs["score"][lo:].data_ptr()
         hd.packed34 = outs["packed34"][lo:].data_ptr()
-        ops.reward_heads(hd)
+        ops.reward_heads(hd, dev)
 
     def _split_batch(self, input_ids: np.ndarray, n_tiles: int, groups: int):
         """[(sample_lo, sample_hi, tile_lo, tile_hi)] - contiguous sample groups with their pixel tiles."""
@@ -737,7 +750,10 @@ class InternVLChatRewardModeling(nn.Module):
             self._pos_table(d, pixel_values.shape[-1] // self.config.vision_config.patch_size, dev)
         groups = self._split_batch(ids_h, pixel_values.shape[0], n_groups)
         try:
-            self._run_groups(d, groups, pixel_values, ids_h, am_h, outs, dev)
+            # the model's device becomes the current device for the whole forward (allocations, events, the library's
+            # per-device kernel attributes), whatever the caller's current device is: model.cuda(1) works like the reference
+            with torch.cuda.device(dev):
+                self._run_groups(d, groups, pixel_values, ids_h, am_h, outs, dev)
         finally:   # the split-K scratch is a process-wide setting of ops: do not leave it behind for other gemm callers
             ops.set_gemm_workspace(None)
         self.last_packed34 = outs.pop("packed34")

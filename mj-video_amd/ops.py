@@ -1,5 +1,6 @@
 """Thin tensor-level wrappers over the C ABI: torch supplies device memory and the current HIP stream,
-every computation happens in libmjv_hip.so.  All functions enqueue on ``torch.cuda.current_stream()``.
+every computation happens in libmjv_hip.so.  Every function enqueues on the current HIP stream OF THE DEVICE ITS
+TENSORS LIVE ON (``torch.cuda.current_stream(t.device)``), never on the process-wide current device's stream.
 """
 from __future__ import annotations
 
@@ -15,8 +16,10 @@ from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_SCALE_RES, EPI_SI
 BF16 = torch.bfloat16
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t: torch.Tensor) -> int:
+    """HIP stream handle for work on ``t``: the current stream of t's device (a model on cuda:1 must not be launched
+    on cuda:0's stream just because cuda:0 is the current device)."""
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -73,7 +76,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     d.out_rows = _p(out_rows)
     if _GEMM_WS is not None and _GEMM_WS.device == a.device:
         d.workspace, d.workspace_bytes = _GEMM_WS.data_ptr(), _GEMM_WS.numel() * _GEMM_WS.element_size()
-    check(lib.mjv_gemm_bf16(C.byref(d), _stream()), "mjv_gemm_bf16")
+    check(lib.mjv_gemm_bf16(C.byref(d), _stream(out)), "mjv_gemm_bf16")
     return out
 
 
@@ -101,7 +104,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     d.n_seqs, d.max_seqlen = cu_seqlens.numel() - 1, max_seqlen
     d.n_heads, d.kv_group, d.head_dim = n_heads, kv_group, head_dim
     d.causal, d.scale, d.score_round_mode = int(causal), scale, score_round_mode
-    check(lib.mjv_attention_bf16(C.byref(d), _stream()), "mjv_attention_bf16")
+    check(lib.mjv_attention_bf16(C.byref(d), _stream(out)), "mjv_attention_bf16")
     return out
 
 
@@ -115,7 +118,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
     lib = load_library()
     rows = out.shape[0] if rows is None else rows
     check(lib.mjv_layernorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), gamma.data_ptr(),
-                                 beta.data_ptr(), rows, out.shape[1], eps, gather_grid, _stream()),
+                                 beta.data_ptr(), rows, out.shape[1], eps, gather_grid, _stream(out)),
           "mjv_layernorm_bf16")
     return out
 
@@ -127,7 +130,7 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, eps: float,
     if row_index is not None:
         assert row_index.dtype == torch.int32 and row_index.is_cuda
     check(lib.mjv_rmsnorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), w.data_ptr(),
-                               _p(row_index), out.shape[0], out.shape[1], eps, _stream()), "mjv_rmsnorm_bf16")
+                               _p(row_index), out.shape[0], out.shape[1], eps, _stream(out)), "mjv_rmsnorm_bf16")
     return out
 
 
@@ -139,7 +142,7 @@ def rope_split(qkv: torch.Tensor, q: torch.Tensor, k: torch.Tensor, cos: torch.T
     lib = load_library()
     check(lib.mjv_rope_split_bf16(qkv.data_ptr(), _row_stride(qkv), q.data_ptr(), _row_stride(q), k.data_ptr(),
                                   _row_stride(k), cos.data_ptr(), sin.data_ptr(), positions.data_ptr(),
-                                  qkv.shape[0], kv_heads, group, _stream()), "mjv_rope_split_bf16")
+                                  qkv.shape[0], kv_heads, group, _stream(qkv)), "mjv_rope_split_bf16")
 
 
 def patchify(pixels: torch.Tensor, patches: torch.Tensor, patch: int) -> torch.Tensor:
@@ -147,7 +150,7 @@ def patchify(pixels: torch.Tensor, patches: torch.Tensor, patch: int) -> torch.T
     assert pixels.is_contiguous() and pixels.dim() == 4 and pixels.shape[1] == 3 and pixels.shape[2] == pixels.shape[3]
     lib = load_library()
     check(lib.mjv_patchify_bf16(pixels.data_ptr(), patches.data_ptr(), _row_stride(patches), pixels.shape[0],
-                                pixels.shape[2], patch, _stream()), "mjv_patchify_bf16")
+                                pixels.shape[2], patch, _stream(patches)), "mjv_patchify_bf16")
     return patches
 
 
@@ -155,7 +158,7 @@ def cls_rows(x: torch.Tensor, cls: torch.Tensor, pos0: torch.Tensor, tiles: int,
     _chk_bf16(x, cls, pos0)
     lib = load_library()
     check(lib.mjv_cls_rows_bf16(x.data_ptr(), _row_stride(x), cls.data_ptr(), pos0.data_ptr(), tiles,
-                                tokens_per_tile, x.shape[1], _stream()), "mjv_cls_rows_bf16")
+                                tokens_per_tile, x.shape[1], _stream(x)), "mjv_cls_rows_bf16")
 
 
 def embed_gather(ids: torch.Tensor, table: torch.Tensor, x: torch.Tensor, skip_id: int) -> None:
@@ -163,12 +166,14 @@ def embed_gather(ids: torch.Tensor, table: torch.Tensor, x: torch.Tensor, skip_i
     assert ids.dtype == torch.int32 and ids.is_cuda
     lib = load_library()
     check(lib.mjv_embed_gather_bf16(ids.data_ptr(), table.data_ptr(), _row_stride(table), x.data_ptr(),
-                                    _row_stride(x), ids.numel(), x.shape[1], skip_id, table.shape[0], _stream()),
+                                    _row_stride(x), ids.numel(), x.shape[1], skip_id, table.shape[0], _stream(x)),
           "mjv_embed_gather_bf16")
 
 
-def reward_heads(desc: HeadsDesc) -> None:
-    check(load_library().mjv_reward_heads_bf16(C.byref(desc), _stream()), "mjv_reward_heads_bf16")
+def reward_heads(desc: HeadsDesc, device: torch.device) -> None:
+    """``device``: where the descriptor's pointers live (a descriptor carries no tensor to take the stream from)."""
+    stream = torch.cuda.current_stream(device).cuda_stream
+    check(load_library().mjv_reward_heads_bf16(C.byref(desc), stream), "mjv_reward_heads_bf16")
 
 
 # ------------------------------------------------------------------------------------ profiler access

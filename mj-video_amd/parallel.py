@@ -22,13 +22,19 @@ def shard_bounds(n_items: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def score_pairs_dp(score_fn: Callable[[Sequence], torch.Tensor], pairs: Sequence, group: Optional[dist.ProcessGroup] = None,
-                   device: Optional[torch.device] = None) -> torch.Tensor:
-    """Scores ``pairs`` data-parallel and returns the full ``[len(pairs), 2, W]`` fp32 block on every rank, in the
-    original pair order (bitwise what a single rank would produce, since per-video math is unchanged).
+SCORE_WIDTH = 34   # score, 5 aspect scores, 28 rewards per video
 
-    ``score_fn(local_pairs) -> [len(local_pairs), 2, W]`` runs the model on this rank's shard (W = 34 for MJ-VIDEO).
-    Works without an initialised process group (single process)."""
+
+def score_pairs_dp(score_fn: Callable[[Sequence], torch.Tensor], pairs: Sequence, group: Optional[dist.ProcessGroup] = None,
+                   device: Optional[torch.device] = None, width: int = SCORE_WIDTH) -> torch.Tensor:
+    """Scores ``pairs`` data-parallel and returns the full ``[len(pairs), 2, width]`` fp32 block on every rank, in the
+    original pair order.  Per-video math does not depend on the sharding except for fp32 summation order inside the GEMMs
+    (tile / split-K choice follows the shard's row count), so a video's numbers on N ranks equal the single-rank ones up
+    to that re-association - and bit for bit whenever the shards have the single-rank batch composition.
+
+    ``score_fn(local_pairs) -> [len(local_pairs), 2, width]`` runs the model on this rank's shard.  The block width is a
+    property of the model (34 for MJ-VIDEO), known to every rank, so the ONLY collective is one ``all_gather_into_tensor``
+    of equal-sized blocks (shards are padded to the largest one).  Works without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()):
         return score_fn(pairs).float()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -38,13 +44,10 @@ def score_pairs_dp(score_fn: Callable[[Sequence], torch.Tensor], pairs: Sequence
     if local is None:
         if device is None:
             raise ValueError("a rank with an empty shard needs `device` to build its (padding) block")
-        width = None
     else:
         device = local.device
-        width = local.shape[-1]
-    w = torch.tensor([width or 0], dtype=torch.int64, device=device)
-    dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
-    width = int(w.item())
+        if local.shape[-1] != width:
+            raise ValueError(f"score_fn returned width {local.shape[-1]}, expected {width} (pass width=...)")
     block = torch.zeros(per, 2, width, dtype=torch.float32, device=device)
     if local is not None:
         block[:hi - lo] = local

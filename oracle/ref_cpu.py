@@ -270,10 +270,18 @@ def reward_forward(sd: Dict[str, torch.Tensor], cfg, pixel_values: torch.Tensor,
         seqlen = seqlen % N
     rows = torch.arange(B)
     h_r = x[rows, seqlen]
-    rewards = F.linear(h_r, sd["regression_layer.weight"])
-    rewards = rewards @ sd["reward_transform_matrix"]
     gpos = [find_token_for_gating(ids.tolist()) for ids in input_ids]
     h_g = x[rows, gpos, :]
+    return reward_heads(sd, cfg, h_r, h_g)
+
+
+@torch.no_grad()
+def reward_heads(sd: Dict[str, torch.Tensor], cfg, h_r: torch.Tensor, h_g: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """moe_reward.py:239-297 - everything downstream of the two hidden-state rows: ``h_r`` [B, hidden] is the
+    post-norm state at the last non-pad token (:229,243), ``h_g`` [B, hidden] at the gating pattern (:242-245)."""
+    B = h_r.shape[0]
+    rewards = F.linear(h_r, sd["regression_layer.weight"])
+    rewards = rewards @ sd["reward_transform_matrix"]
 
     T = cfg.gating_temperature
     nl = cfg.gating_n_hidden + 1

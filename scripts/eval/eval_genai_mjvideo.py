@@ -86,7 +86,7 @@ def evaluate_examples(model, config, tokenizer, examples, pixel_loader, pairs_pe
             chunk = [dict(prompt=ex["prompt"], left_pixels=pixel_loader(ex["left_video"]),
                           right_pixels=pixel_loader(ex["right_video"])) for ex in local[i:i + pairs_per_batch]]
             blocks.append(harness.score_pair_batch(model, config, tokenizer, chunk, generation_config).float())
-        return torch.cat(blocks) if blocks else torch.zeros(0, 2, 1, device=model.model.device)
+        return torch.cat(blocks) if blocks else torch.zeros(0, 2, parallel.SCORE_WIDTH, device=model.model.device)
 
     scores = parallel.score_pairs_dp(score_fn, list(examples), device=model.model.device)
     s = scores[..., 0].cpu()

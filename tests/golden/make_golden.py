@@ -203,11 +203,88 @@ def gen_rankset(tag: str, S: int, pairs: int, wseed: int, pixel_seed: int, fp32_
                       open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
 
 
+def _bits(t: torch.Tensor) -> np.ndarray:
+    """bf16 tensor -> its uint16 bit patterns."""
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def gen_rankhid(tag: str, S: int, pairs: int, wseed: int, pixel_seed: int, fp32_every: int, n_tiles: int = 8,
+                old_tag: str = None):
+    """BACKBONE pass of the reference over the rank set's videos (same seeds as ``gen_rankset``): stores the two
+    hidden-state rows the heads read (``hidden_state`` = h_r, ``prompt_embedding`` = h_g; bf16 bit patterns), the 34
+    output numbers under the default synthetic heads, and the same from an fp32 run of every ``fp32_every``-th pair.
+    Everything downstream of (h_r, h_g) is a function of the head weights only (moe_reward.py:239-297), so other
+    head weights can be scored against the reference later by running the reference's own head code on these rows
+    (``rankset_eng``) without repeating the backbone.  For every video it also REQUIRES
+    ``ref_cpu.reward_heads(h_r, h_g)`` == the reference's outputs bit for bit."""
+    cd, hk, cfg = make_cfg("2b", S)
+    sd = synth.synth_state_dict(cfg, seed=wseed)
+    model = RS.build_reference_model(cd, hk, sd, torch.bfloat16, synth.IMG_CONTEXT_ID, synth.PAD_ID)
+    sd_f = {k: t.float() for k, t in sd.items()} if fp32_every else None
+    H = cfg.llm_config.hidden_size
+    n32 = (pairs + fp32_every - 1) // fp32_every if fp32_every else 0
+    A = dict(hr_bf16=np.zeros((pairs, 2, H), np.uint16), hg_bf16=np.zeros((pairs, 2, H), np.uint16),
+             out34=np.zeros((pairs, 2, 34), np.float32),
+             hr_fp32=np.zeros((n32, 2, H), np.float32), hg_fp32=np.zeros((n32, 2, H), np.float32),
+             out34_fp32=np.zeros((n32, 2, 34), np.float32))
+    path = os.path.join(HERE, f"{tag}.npz")
+    first = 0
+    if RESUME and os.path.isfile(path):
+        old = np.load(path)
+        first = min(int(old["done"]), pairs)
+        for k in A:
+            n = min(old[k].shape[0], A[k].shape[0])
+            A[k][:n] = old[k][:n]
+        print(f"[{tag}] resuming after {first} pairs", flush=True)
+    prev = None
+    if old_tag and os.path.isfile(os.path.join(HERE, f"{old_tag}.npz")):
+        prev = np.load(os.path.join(HERE, f"{old_tag}.npz"))["ref_bf16"]
+    t_start = time.time()
+    mism = 0
+
+    def pack34(r, row):
+        row[0] = r["score"].item()
+        row[1:6] = r["aspect_scores"][0].float().numpy()
+        row[6:] = r["rewards"][0].float().numpy()
+
+    for p in range(first, pairs):
+        ids = synth.synth_input_ids(n_img_tokens(cfg, n_tiles), caption_seed=1000 + p)
+        mask = torch.ones_like(ids)
+        for j in range(2):
+            px = synth.synth_pixel_values(pixel_seed, 2 * p + j, n_tiles, S)
+            r = run_reference(model, px, ids, mask)
+            heads = ref_cpu.reward_heads(sd, cfg, r["hidden_state"], r["prompt_embedding"])
+            check_equal(r, heads, f"{tag}: heads-from-hidden-rows, pair {p} video {j}")
+            A["hr_bf16"][p, j] = _bits(r["hidden_state"][0])
+            A["hg_bf16"][p, j] = _bits(r["prompt_embedding"][0])
+            pack34(r, A["out34"][p, j])
+            if prev is not None and p < prev.shape[0] and not np.array_equal(prev[p, j], A["out34"][p, j]):
+                mism += 1
+            if fp32_every and p % fp32_every == 0:
+                f = ref_cpu.reward_forward(sd_f, cfg, px.float(), ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID)
+                q = p // fp32_every
+                A["hr_fp32"][q, j] = f["hidden_state"][0].numpy()
+                A["hg_fp32"][q, j] = f["prompt_embedding"][0].numpy()
+                pack34(f, A["out34_fp32"][q, j])
+        print(f"[{tag}] pair {p}: {A['out34'][p, 0, 0]:+.5f} {A['out34'][p, 1, 0]:+.5f}  "
+              f"({time.time() - t_start:.0f}s, {mism} videos differ from {old_tag})", flush=True)
+        if p % 8 == 7 or p == pairs - 1:
+            np.savez_compressed(path + ".tmp.npz", done=np.int64(p + 1), **A)
+            os.replace(path + ".tmp.npz", path)
+            json.dump(dict(kind="2b", image_size=S, weight_seed=wseed, pixel_seed=pixel_seed, pairs=p + 1,
+                           n_tiles=n_tiles, caption_seed_base=1000, fp32_every=fp32_every,
+                           cpu_threads=torch.get_num_threads(), videos_differing_from_old_set=mism,
+                           layout="hr/hg: [pair, video, hidden] (bf16 bit patterns / fp32 of every fp32_every-th pair); "
+                                  "out34: [pair, video, (score, aspect_scores[5], rewards[28])] under the default heads"),
+                      open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["tiny", "full_c1", "full_c2", "rankset_c1", "rankset_c2"])
+    ap.add_argument("what", choices=["tiny", "full_c1", "full_c2", "rankset_c1", "rankset_c2", "rankhid_c1", "rankhid_c2"])
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--fp32-every", type=int, default=4, help="rankhid: fp32 run of every n-th pair")
     ap.add_argument("--resume", action="store_true", help="rank sets: keep the pairs already in the fixture and append")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -222,3 +299,7 @@ if __name__ == "__main__":
         gen_rankset("rankset_c1", 224, a.pairs, wseed=0, pixel_seed=400, fp32_every=4)
     elif a.what == "rankset_c2":
         gen_rankset("rankset_c2", 448, a.pairs, wseed=0, pixel_seed=500, fp32_every=8)
+    elif a.what == "rankhid_c1":
+        gen_rankhid("rankhid_c1", 224, a.pairs, wseed=0, pixel_seed=400, fp32_every=a.fp32_every, old_tag="rankset_c1")
+    elif a.what == "rankhid_c2":
+        gen_rankhid("rankhid_c2", 448, a.pairs, wseed=0, pixel_seed=500, fp32_every=a.fp32_every, old_tag="rankset_c2")

@@ -211,6 +211,20 @@ def test_checkpoint_directory_ingestion_and_setup_order(tmp_path):
         InternVLChatRewardModeling(str(tmp_path), re_cfg)
 
 
+def test_missing_base_weights_fail_loudly(tmp_path):
+    """The reference's ``from_pretrained`` returns real base weights or fails (moe_reward.py:142); a directory without
+    ``*.safetensors`` (or a hub name, which cannot be resolved offline) must not yield a torch.empty model silently."""
+    from mj_video_amd.modeling import InternVLChatModel
+    cfg = make_cfg("tiny", 56)
+    cfg.save_pretrained(str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="safetensors"):
+        InternVLChatRewardModeling(str(tmp_path), cfg)
+    with pytest.raises(FileNotFoundError):
+        InternVLChatModel.from_pretrained("OpenGVLab/InternVL2-2B", config=cfg)
+    skeleton = InternVLChatModel.from_pretrained(str(tmp_path), config=cfg, allow_uninitialized=True)
+    assert skeleton.num_image_token == 4
+
+
 def test_model_refuses_cpu_and_non_bf16():
     cfg = make_cfg("tiny", 56)
     model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16)
@@ -218,6 +232,25 @@ def test_model_refuses_cpu_and_non_bf16():
     model.model.img_context_token_id = synth.IMG_CONTEXT_ID
     with pytest.raises(RuntimeError, match="MI355X only"):
         model.forward(torch.zeros(2, 3, 56, 56, dtype=torch.bfloat16), synth.synth_input_ids(8, 1), None)
+
+
+def test_token_ids_outside_the_vocabulary_raise():
+    """nn.Embedding raises on an id outside [0, vocab) (modeling_internvl_chat.py:161); the gather kernel would read out
+    of bounds silently, so the host check stands in for it.  Pad ids in the masked tail are never looked up."""
+    cfg = make_cfg("tiny", 56)
+    model = InternVLChatRewardModeling.from_config(cfg)
+    model.model.img_context_token_id = synth.IMG_CONTEXT_ID
+    model.config.pad_token_id = synth.PAD_ID
+    vocab = cfg.llm_config.vocab_size
+    ids = synth.synth_input_ids(8, 1).numpy().copy()
+    model._analyse_ids(ids, None, 2)
+    bad = ids.copy()
+    bad[0, 5] = vocab
+    with pytest.raises(IndexError, match="out of range"):
+        model._analyse_ids(bad, None, 2)
+    bad[0, 5] = -3
+    with pytest.raises(IndexError, match="out of range"):
+        model._analyse_ids(bad, None, 2)
 
 
 def test_analyse_ids_packing():
