@@ -114,8 +114,12 @@ typedef struct mjv_attn_desc {
 } mjv_attn_desc;
 
 int mjv_attention_bf16(const mjv_attn_desc* d, void* stream);
-/* kernel schedule selector for A/B measurements; only 0 (the production schedule) is built in at present, any other
- * value returns MJV_E_ARG */
+/* timing-experiment selector (tools/attn_bench.py; process-wide, never needed for results): 0 = production; on the two
+ * production shapes (D = 64 non-causal with a power-of-two scale, D = 128 causal mode 1) 1 = K/V staged once (no
+ * barriers / LDS stores / global loads after the first tile), 2 = softmax removed, 3 = MFMAs removed - wrong results by
+ * construction, they attribute the kernel's time.  Other values return MJV_E_ARG.
+ * max_seqlen MUST be >= the longest sequence of cu_seqlens: query rows beyond it are not computed (their O rows are
+ * left untouched). */
 int mjv_attention_set_variant(int32_t variant);
 
 /* LayerNorm over the last dim, fp32 statistics, bf16 out (nn.LayerNorm on bf16:

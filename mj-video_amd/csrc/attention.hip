@@ -100,7 +100,10 @@ MJV_DEV float round_score(float a, float scale) {
   return rbf(a);  // RM_POW2: the scale is folded into the exp2 argument
 }
 
-template <int D, bool CAUSAL, int RM>
+// VAR: 0 = production.  Timing experiments (wrong results by construction, tools/attn_bench.py only; selected with
+// mjv_attention_set_variant): 1 = K/V staged once (no barriers, no LDS stores, no global loads after tile 0),
+// 2 = softmax removed (P = bf16(S)), 3 = MFMAs removed (LDS reads and the softmax kept).
+template <int D, bool CAUSAL, int RM, int VAR = 0>
 __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p) {
   using C = Cfg<D>;
   __shared__ __attribute__((aligned(16))) char smem[C::K_BYTES + C::V_BYTES];
@@ -251,7 +254,12 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[t2][r] = 0.f;
         }
-        sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i % RING], qf[ks], sacc[t2], 0, 0, 0);
+        if constexpr (VAR == 3) {
+          asm volatile("" ::"v"(kr[i % RING]));
+          sacc[t2][ks] += (float)lane * 1e-3f;
+        } else {
+          sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i % RING], qf[ks], sacc[t2], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -263,7 +271,12 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) {
           const bf16x8 kf = *(const bf16x8*)(kp + ks * 32);
-          sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t2], 0, 0, 0);
+          if constexpr (VAR == 3) {
+            asm volatile("" ::"v"(kf));
+            sacc[t2][ks] += (float)lane * 1e-3f;
+          } else {
+            sacc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[t2], 0, 0, 0);
+          }
         }
       }
     }
@@ -281,6 +294,18 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
           if (key >= len || (CAUSAL && key > qi)) sacc[t2][r] = -INFINITY;
         }
     }
+    bf16x8 pf[2][2];
+    if constexpr (VAR == 2) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        unsigned pw[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) pw[r >> 1] = pack_pair(f32x2{sacc[t2][r], sacc[t2][r + 1]});
+        pf[t2][0] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+        pf[t2][1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
+      }
+      l_run = 1.f;
+    } else {
     // ---- online softmax.  bf16 rounding is monotone, so the row max is taken on the raw accumulators and rounded once.
     float mx = sacc[0][0];
 #pragma unroll
@@ -303,7 +328,6 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
     const f32x2 c2 = {c_exp, c_exp};
     const f32x2 nmb2 = {-m_run * c_exp, -m_run * c_exp};
     f32x2 psum2 = {0.f, 0.f};
-    bf16x8 pf[2][2];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
       unsigned pw[8];
@@ -322,6 +346,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
       pf[t2][1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
     }
     l_run += xhalf_sum(psum2[0] + psum2[1]);
+    }
 
     // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads.
     // element j of the fragment <-> key 32*t2 + 16*s2 + 8*(j>>2) + 4*hi + (j&3)
@@ -348,7 +373,12 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 #pragma unroll
       for (int i = 0; i < N_PV; ++i) {
         if (i + AHEAD < N_PV) read_v(i + AHEAD, fr[(i + AHEAD) % RING]);
-        oacc[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % RING], pf[(i >> 1) & 1][i & 1], oacc[i >> 2], 0, 0, 0);
+        if constexpr (VAR == 3) {
+          asm volatile("" ::"v"(fr[i % RING]), "v"(pf[(i >> 1) & 1][i & 1]));
+          oacc[i >> 2][i & 3] += l_run;
+        } else {
+          oacc[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % RING], pf[(i >> 1) & 1][i & 1], oacc[i >> 2], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -362,10 +392,12 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
   } else {
     load_tile(0);
     for (int kt = 0; kt < n_tiles; ++kt) {
-      __syncthreads();  // previous tile fully consumed
-      store_tile();
-      __syncthreads();
-      tile_math(kt, kt + 1 < n_tiles);
+      if (VAR != 1 || kt == 0) {
+        __syncthreads();  // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+      }
+      tile_math(kt, VAR != 1 && kt + 1 < n_tiles);
     }
   }
 
@@ -392,6 +424,8 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 // levers that paid were the ones that remove work or traffic: XCD-aware placement, leaner staging addresses, scalar
 // control flow, heaviest-first causal order, the one-wave ragged block.
 
+int g_attn_variant = 0;
+
 template <int D, bool CAUSAL>
 int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
   int e;
@@ -400,6 +434,12 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
   a.n_qb = (max_seqlen + QB - 1) / QB;
   const int total = a.n_qb * a.n_heads * n_seqs;
   const dim3 grid(8 * ((total + 7) / 8));
+  if constexpr ((D == 64 && !CAUSAL) || (D == 128 && CAUSAL)) {   // timing experiments on the two production shapes
+    constexpr int RMX = (D == 64) ? RM_POW2 : RM_DIV;
+    if (g_attn_variant == 1) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 1>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
+    if (g_attn_variant == 2) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 2>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
+    if (g_attn_variant == 3) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 3>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
+  }
   if (a.round_mode == 1) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV>), grid, dim3(256), 0, s, a);
   else if (pow2) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_POW2>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_MUL>), grid, dim3(256), 0, s, a);
@@ -409,10 +449,11 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
 }  // namespace
 
 extern "C" int mjv_attention_set_variant(int32_t v) {
-  if (v != 0) {   // kept in the ABI for A/B experiments; one schedule is built in at present
-    mjv_set_error("attention_set_variant: %d not in {0}", v);
+  if (v < 0 || v > 3) {   // 0 = production; 1-3 = the timing experiments documented at attn_kernel
+    mjv_set_error("attention_set_variant: %d not in {0..3}", v);
     return MJV_E_ARG;
   }
+  g_attn_variant = v;
   return MJV_OK;
 }
 
