@@ -596,6 +596,8 @@ class InternVLChatRewardModeling(nn.Module):
             ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_BIAS)
             ops.rope_split(qkv, q, k, cos, sin, positions, KV, G)
             ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, 1, v_head_stride=(G + 2) * hd)
+            if self.debug_probes is not None and li == 0:   # operands / result of the first causal attention (parity tests)
+                self.debug_probes["llm_attn0"] = dict(q=q.clone(), k=k.clone(), v=v_view.clone(), out=hn.clone(), kv_heads=KV)
             if li == last and sel_rows is not None and self.debug_probes is None:
                 ns = sel_rows.numel()
                 att_s = self._buf("llm_att_sel", ns, hdim, dev)
@@ -651,6 +653,13 @@ class InternVLChatRewardModeling(nn.Module):
         else:
             ops.rmsnorm(hidden, norm_w, h_r, lc.rms_norm_eps, row_index=sel_rows[:B])
             ops.rmsnorm(hidden, norm_w, h_g, lc.rms_norm_eps, row_index=sel_rows[B:])
+        self._run_heads(d, h_r, h_g, outs, lo, B, dev)
+
+    def _run_heads(self, d, h_r: torch.Tensor, h_g: torch.Tensor, outs, lo: int, B: int, dev):
+        """moe_reward.py:239-297 on the two (post-norm) hidden-state rows per sample: the gating MLPs' hidden layers as
+        batch-sized GEMMs, everything else (regression matvec, last gating layers, the softmaxes, the weighted sums) in
+        one ``reward_heads`` launch.  Writes rows [lo, lo + B) of ``outs``."""
+        hdim = self.config.llm_config.hidden_size
         gh = self.aspect_gating.layers[0].out_features
 
         def gating_hidden(net: GatingNetwork, name: str) -> torch.Tensor:
@@ -684,6 +693,43 @@ class InternVLChatRewardModeling(nn.Module):
         hd.score = outs["score"][lo:].data_ptr()
         hd.packed34 = outs["packed34"][lo:].data_ptr()
         ops.reward_heads(hd, dev)
+
+    def _alloc_outputs(self, B: int, dev) -> Dict[str, torch.Tensor]:
+        hdim = self.config.llm_config.hidden_size
+        nobj, nasp = self.num_objectives, self.num_aspects
+        return dict(
+            rewards=torch.empty(B, nobj, dtype=BF16, device=dev),
+            hidden_state=torch.empty(B, hdim, dtype=BF16, device=dev),
+            prompt_embedding=torch.empty(B, hdim, dtype=BF16, device=dev),
+            criteria_gating_output=torch.empty(B, nobj, dtype=BF16, device=dev),
+            aspect_gating_output=torch.empty(B, nasp, dtype=BF16, device=dev),
+            aspect_weights=torch.empty(B, nobj, dtype=BF16, device=dev),
+            weighted_scores=torch.empty(B, dtype=BF16, device=dev),
+            aspect_scores=torch.empty(B, nasp, dtype=torch.float32, device=dev),
+            score=torch.empty(B, dtype=torch.float32, device=dev),
+            packed34=torch.empty(B, 1 + nasp + nobj, dtype=torch.float32, device=dev))
+
+    @torch.no_grad()
+    def heads_forward(self, hidden_state: torch.Tensor, prompt_embedding: torch.Tensor) -> CustomOutput:
+        """Everything downstream of the backbone (moe_reward.py:239-297) on given post-norm rows: ``hidden_state``
+        [B, hidden] = state at the last non-pad token, ``prompt_embedding`` [B, hidden] = state at the gating pattern.
+        Not part of the reference's API: the entry the isolated head-kernel tests and the engineered rank sets use
+        (same code path ``forward`` ends with)."""
+        dev = self.model.device
+        if dev.type != "cuda":
+            raise RuntimeError("heads_forward runs on the MI355X only")
+        d = self._prepare(dev)
+        h_r = hidden_state.to(dev, BF16).contiguous()
+        h_g = prompt_embedding.to(dev, BF16).contiguous()
+        B = h_r.shape[0]
+        outs = self._alloc_outputs(B, dev)
+        outs["hidden_state"].copy_(h_r)
+        outs["prompt_embedding"].copy_(h_g)
+        self._ws_tag = "g0"
+        with torch.cuda.device(dev):
+            self._run_heads(d, outs["hidden_state"], outs["prompt_embedding"], outs, 0, B, dev)
+        self.last_packed34 = outs.pop("packed34")
+        return CustomOutput(**outs)
 
     def _split_batch(self, input_ids: np.ndarray, n_tiles: int, groups: int):
         """[(sample_lo, sample_hi, tile_lo, tile_hi)] - contiguous sample groups with their pixel tiles."""
@@ -729,19 +775,7 @@ class InternVLChatRewardModeling(nn.Module):
         B = input_ids.shape[0]
         if self.config.pad_token_id is None and B != 1:   # moe_reward.py:218-219
             raise ValueError("Cannot handle batch sizes > 1 if no padding token is defined.")
-        hdim = self.config.llm_config.hidden_size
-        nobj, nasp = self.num_objectives, self.num_aspects
-        outs = dict(
-            rewards=torch.empty(B, nobj, dtype=BF16, device=dev),
-            hidden_state=torch.empty(B, hdim, dtype=BF16, device=dev),
-            prompt_embedding=torch.empty(B, hdim, dtype=BF16, device=dev),
-            criteria_gating_output=torch.empty(B, nobj, dtype=BF16, device=dev),
-            aspect_gating_output=torch.empty(B, nasp, dtype=BF16, device=dev),
-            aspect_weights=torch.empty(B, nobj, dtype=BF16, device=dev),
-            weighted_scores=torch.empty(B, dtype=BF16, device=dev),
-            aspect_scores=torch.empty(B, nasp, dtype=torch.float32, device=dev),
-            score=torch.empty(B, dtype=torch.float32, device=dev),
-            packed34=torch.empty(B, 1 + nasp + nobj, dtype=torch.float32, device=dev))
+        outs = self._alloc_outputs(B, dev)
         ids_h, am_h = self._host_ids(input_ids, attention_mask)
         n_groups = 1 if self.debug_probes is not None else self.n_streams
         # shared lazily-built tables must exist before the streams fork

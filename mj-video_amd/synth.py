@@ -132,6 +132,50 @@ def synth_state_dict(config, seed: int = 0, dtype=torch.bfloat16, head_std: floa
         return dict(pool.map(make, items))
 
 
+def synth_head_state_dict(config, seed: int = 0, dtype=torch.bfloat16, head_std: float = 0.05,
+                          gate_std: float = 0.05) -> Dict[str, torch.Tensor]:
+    """Only the reward / gating head tensors of ``synth_state_dict`` (identical values: every tensor has its own
+    Philox stream), i.e. every checkpoint key outside ``model.*``."""
+    out = {}
+    for key, shape, kind in state_dict_spec(config):
+        if key.startswith("model."):
+            continue
+        if kind == "head":
+            t = _normal(seed, key, shape, head_std)
+        elif kind == "gate":
+            t = _normal(seed, key, shape, gate_std)
+        elif kind == "b":
+            t = _normal(seed, key, shape, 0.02)
+        elif kind == "eye":
+            t = torch.eye(shape[0], dtype=torch.float32)
+        elif kind == "one":
+            t = torch.ones(shape, dtype=torch.float32)
+        else:
+            raise AssertionError((key, kind))
+        out[key] = t.to(dtype)
+    return out
+
+
+def engineered_head_state_dict(config, seed: int, regression_weight: torch.Tensor, gate_dirs: np.ndarray,
+                               dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Head weights of the ENGINEERED rank sets (tests/golden/rankeng_*.npz, made by make_golden.gen_rankset_eng): the
+    synthetic heads of ``synth_head_state_dict`` with (a) the stored regression matrix and (b) first gating layers whose
+    rows are random mixes of ``gate_dirs`` ([n, hidden]: leading principal directions of the gating-row hidden state,
+    each divided by its inter-video spread).  The mix is a pure function of ``seed`` and the product is formed
+    elementwise in float64 in a fixed order, so the build container and the GPU box get bit-identical bf16 weights
+    (the fixture stores their checksum)."""
+    sd = synth_head_state_dict(config, seed=seed, dtype=dtype)
+    sd["regression_layer.weight"] = regression_weight.to(dtype)
+    d = np.asarray(gate_dirs, dtype=np.float64)
+    for net in ("aspect_gating", "criteria_gating"):
+        key = f"{net}.layers.0.weight"
+        rows = sd[key].shape[0]
+        m = _rng(seed, key + "/engineered-mix").standard_normal((rows, d.shape[0]))
+        w = (m[:, :, None] * d[None, :, :]).sum(axis=1)
+        sd[key] = torch.from_numpy(w.astype(np.float32)).to(dtype)
+    return sd
+
+
 def synth_pixel_values(seed: int, video_idx: int, n_tiles: int, image_size: int,
                        dtype=torch.bfloat16) -> torch.Tensor:
     """One synthetic video, already in normalised-pixel space: ``[n_tiles, 3, S, S]``.

@@ -91,3 +91,59 @@ def build_reference_model(config_dict: dict, head_kwargs: dict, state_dict: dict
     model.model.img_context_token_id = img_context_token_id
     model.eval()
     return model
+
+
+def build_reference_heads(config_dict: dict, head_kwargs: dict, head_state_dict: dict, dtype, pad_token_id):
+    """The reference's InternVLChatRewardModeling with its OWN head code (moe_reward.py:213-297) and a backbone
+    replaced by a replay stub: ``model.replay(h_r, h_g)`` runs the reference's ``forward`` on hidden states whose
+    reward row (last non-pad token, :218-229) and gating row (the ``<|im_end|><|im_start|>assistant\\n`` pattern, :242-243)
+    are the given ``[B, hidden]`` tensors.  Used to score OTHER head weights on backbone outputs that an earlier (expensive)
+    reference run stored: everything downstream of those two rows is a function of the head weights only.
+    The backbone that ``__init__`` constructs is shrunk to one layer per tower (it is never executed)."""
+    import torch
+    mr = load_reference()
+    from internvl2 import InternVLChatModel, InternVLChatConfig
+
+    cd = copy.deepcopy(config_dict)
+    cd["vision_config"]["num_hidden_layers"] = 1
+    cd["llm_config"]["num_hidden_layers"] = 1
+    cd["llm_config"]["vocab_size"] = 128
+    cfg = mr.InternVLChatRewardModelingConfig(**copy.deepcopy(cd), **copy.deepcopy(head_kwargs))
+    orig = InternVLChatModel.from_pretrained
+    InternVLChatModel.from_pretrained = staticmethod(lambda name, *a, **k: InternVLChatModel(InternVLChatConfig(**copy.deepcopy(cd))))
+    try:
+        model = mr.InternVLChatRewardModeling("synthetic-heads", cfg)
+    finally:
+        InternVLChatModel.from_pretrained = orig
+    head_keys = {k: v for k, v in head_state_dict.items() if not k.startswith("model.")}
+    res = model.load_state_dict(head_keys, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("model.") for k in res.missing_keys), res
+    model.config.pad_token_id = pad_token_id
+    model = model.to(dtype).eval()
+    pattern = list(mr.token_pattern)
+    ids = torch.tensor([[7] + pattern], dtype=torch.long)   # reward row = last index, gating row = 1; no pad id inside
+    assert pad_token_id not in ids[0].tolist()
+
+    class _Out:
+        pass
+
+    state = {}
+
+    def _backbone(*a, **k):
+        o = _Out()
+        o.hidden_states = (state["h"],)
+        return o
+
+    model.model.forward = _backbone
+
+    def replay(h_r, h_g):
+        B, H = h_r.shape
+        h = torch.zeros(B, ids.shape[1], H, dtype=h_r.dtype)
+        h[:, -1] = h_r
+        h[:, 1] = h_g
+        state["h"] = h
+        with torch.no_grad():
+            return model.forward(None, ids.expand(B, -1), None)
+
+    model.replay = replay
+    return model

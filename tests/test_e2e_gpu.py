@@ -60,6 +60,41 @@ def pooled_noise_floor(field):
     return worst
 
 
+def pooled_noise_rms(field):
+    """rms of (ref_bf16 - ref_fp32) of ``field`` over every MJ-VIDEO-2B-dims fixture with an fp32 run (same pool as
+    pooled_noise_floor)."""
+    sq, n = 0.0, 0
+    for tag in ("full_c1", "full_c2"):
+        npz, meta = load_golden(tag)
+        for v in meta["videos"]:
+            p = f"v{v['video_idx']}"
+            if f"{p}/fp32/{field}" in npz.files:
+                dlt = (npz[f"{p}/{field}"] - npz[f"{p}/fp32/{field}"]).astype(np.float64).ravel()
+                sq, n = sq + float((dlt ** 2).sum()), n + dlt.size
+    for tag in ("rankset_c1", "rankset_c2"):
+        try:
+            npz, _ = load_golden(tag)
+        except FileNotFoundError:
+            continue
+        b, f = npz["ref_bf16"][..., _PACKED34[field]], npz["ref_fp32"][..., _PACKED34[field]]
+        have = ~np.isnan(f[:, 0, 0])
+        dlt = (b[have] - f[have]).astype(np.float64).ravel()
+        sq, n = sq + float((dlt ** 2).sum()), n + dlt.size
+    return float(np.sqrt(sq / max(n, 1)))
+
+
+def bits_to_f32(a):
+    """bf16 bit patterns (uint16) -> float32 values"""
+    return (a.astype(np.uint32) << 16).view(np.float32)
+
+
+# relative-L2 bound of a layer's hidden state against the reference's bf16 run at MJ-VIDEO-2B dims.  The reference's own
+# bf16 run is 2.4-2.7 % away from its fp32 run at the END of the language tower (tools/parity_report.py), the error grows
+# layer by layer, and two samples of that noise differ by sqrt(2) x one: 3 % for the vision tower (24 layers, LayerScale-
+# damped residual updates), 4 % for the language tower's deepest layers.
+LAYER_TOL = {"vit": 0.03, "llm": 0.04}
+
+
 def rel_l2(a, b):
     a, b = a.astype(np.float64), b.astype(np.float64)
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
@@ -81,6 +116,8 @@ def test_tiny_cases_against_golden(cuda):
         torch.cuda.synchronize()
         # layer-by-layer first: localises a broken kernel instead of a vague score mismatch
         for key, t in model.debug_probes.items():
+            if not isinstance(t, torch.Tensor):
+                continue   # operand captures (llm_attn0) are for the attention cross-checks, not layer states
             ref = npz[f"{name}/probe/{key}"]
             got = t.float().cpu().numpy()
             if key.startswith("llm_"):
@@ -124,6 +161,8 @@ def _full_case(cuda, tag, image_size):
     torch.cuda.synchronize()
     probes = model.debug_probes
     tiles = meta["videos"][0]["n_tiles"]
+    cu_rows = np.concatenate([[0], np.cumsum([int(m.sum()) for m in mask])])
+    layer_report, dev_by_field = [], {f: [] for f in _PACKED34}
     for i, v in enumerate(meta["videos"]):
         p = f"v{v['video_idx']}"
         if f"{p}/probe/vit_embed_head" in npz.files:
@@ -131,6 +170,28 @@ def _full_case(cuda, tag, image_size):
             for key, src in (("vit_embed_head", "vit_embed"), ("vit_layer0_head", "vit_layer0"), ("vit_embeds_head", "vit_embeds")):
                 got = probes[src][sl, :4, :16].float().cpu().numpy()
                 assert rel_l2(got, npz[f"{p}/probe/{key}"]) < 0.03, (tag, p, key, rel_l2(got, npz[f"{p}/probe/{key}"]))
+            # language tower: the last 4 token rows of the first and the last decoder layer (packed rows of this video)
+            lo_row, hi_row = int(cu_rows[i]), int(cu_rows[i + 1])
+            nl = cfg.llm_config.num_hidden_layers
+            for key, src in (("llm_layer0_tail", "llm_layer0"), ("llm_last_tail", f"llm_layer{nl - 1}")):
+                got = probes[src][hi_row - 4:hi_row, :16].float().cpu().numpy()
+                e = rel_l2(got, npz[f"{p}/probe/{key}"])
+                assert e < LAYER_TOL[src.split("_")[0]], (tag, p, key, e)
+            # whole-row samples of several layers of both towers at MJ-VIDEO-2B dims (thousands of elements per probe)
+            rp = meta.get("row_probes")
+            if rp and f"{p}/probe/vit_layer{rp['vit_layers'][0]}_rows" in npz.files:
+                for L in rp["vit_layers"]:
+                    ref = bits_to_f32(npz[f"{p}/probe/vit_layer{L}_rows"])
+                    got = probes[f"vit_layer{L}"][i * tiles, :rp["vit_rows"], :].float().cpu().numpy()
+                    e = rel_l2(got, ref)
+                    layer_report.append((tag, p, f"vit{L}", round(e, 4)))
+                    assert e < LAYER_TOL["vit"], (tag, p, "vit_layer", L, e)
+                for L in rp["llm_layers"]:
+                    ref = bits_to_f32(npz[f"{p}/probe/llm_layer{L}_rows"])
+                    got = probes[f"llm_layer{L}"][hi_row - rp["llm_rows"]:hi_row, :].float().cpu().numpy()
+                    e = rel_l2(got, ref)
+                    layer_report.append((tag, p, f"llm{L}", round(e, 4)))
+                    assert e < LAYER_TOL["llm"], (tag, p, "llm_layer", L, e)
         for f in FIELDS:
             got = getattr(out, f)[i].float().cpu().numpy()
             ref = npz[f"{p}/{f}"][0]
@@ -141,6 +202,17 @@ def _full_case(cuda, tag, image_size):
             d = float(np.abs(got - ref).max())
             print(f"{tag} {p} {f}: max|d|={d:.3e} tol={tol:.3e}")
             assert d <= tol, f"{tag}:{p}:{f} max|d|={d:.4e} > tol {tol:.4e}"
+            if f in dev_by_field:
+                dev_by_field[f].append((got - ref).ravel())
+    # the statements that bite at MJ-VIDEO-2B dims: over the fixture's videos the HIP path deviates from the reference's
+    # bf16 run, in the rms sense, by no more than 2 x what the reference's bf16 run deviates from its own fp32 run
+    # (the difference of two samples of one noise is sqrt(2) x one sample), and every probed layer stays within LAYER_TOL
+    for f, devs in dev_by_field.items():
+        rms = float(np.sqrt(np.mean(np.concatenate(devs) ** 2)))
+        ref_rms = pooled_noise_rms(f)
+        print(f"{tag} {f}: rms(hip - ref) over {len(devs)} videos = {rms:.4f}; reference bf16-vs-fp32 rms = {ref_rms:.4f}")
+        assert rms <= 2.0 * ref_rms + ATOL_FLOOR, (tag, f, rms, ref_rms)
+    print("layer probes (relative L2 vs the reference):", layer_report)
     return model, cfg
 
 
@@ -154,38 +226,37 @@ def test_full_c2_against_golden(cuda):
     _full_case(cuda, "full_c2", 448)
 
 
-def test_rank_agreement_c1(cuda):
-    """256 pairs at MJ-VIDEO-2B dims, 8 frames @224 (BASELINE.json configs[0] shape)"""
-    _rank_case(cuda, "rankset_c1", pairs_per_forward=8)
+_RANK_CACHE = {}
 
 
-def test_rank_agreement_c2(cuda):
-    """Pairs at the headline shape (8 frames @448, N = 2186, BASELINE.json configs[1]); the set is smaller because every
-    pair costs the reference about a minute of CPU time."""
-    _rank_case(cuda, "rankset_c2", pairs_per_forward=4)
+def _head_checksum(sd):
+    import hashlib
+    return hashlib.sha1(b"".join(sd[k].contiguous().view(torch.int16).numpy().tobytes() for k in sorted(sd))).hexdigest()
 
 
-def _rank_case(cuda, name, pairs_per_forward):
-    """Fixed synthetic set of pairs scored by the reference: the HIP scores must (1) deviate from the reference no
-    more than the reference deviates from its own fp32 run, (2) give the same pairwise preference on >= 0.999 of the
-    decisive pairs (margin > 12 x the reference's noise rms), (3) the same good/bad flag, (4) rank mutually separated scores identically
-    (Spearman >= 0.999); near-ties are reported, not hidden."""
+def _rank_run(cuda, name, pairs_per_forward):
+    """Scores every pair of rank set ``name`` ONCE per session (the backbone pass is the expensive part) and returns
+    dict(meta, got [P,2,34] under the default synthetic heads, eng [P,2,34] under the engineered heads of
+    rankeng_* - computed by ``heads_forward`` on the hidden rows of the very same forwards - or None)."""
+    if name in _RANK_CACHE:
+        return _RANK_CACHE[name]
     from mj_video_amd import synth
     from mj_video_amd.chat_input import num_image_tokens_per_tile
     try:
         npz, meta = load_golden(name)
     except FileNotFoundError:
         pytest.skip(f"{name} fixture not generated")
-    ref = npz["ref_bf16"]
-    ref32 = npz["ref_fp32"]
-    P = ref.shape[0]
+    P = npz["ref_bf16"].shape[0]
     cfg = make_cfg("2b", meta["image_size"])
     sd = synth.synth_state_dict(cfg, seed=meta["weight_seed"], lm_head=False)
     sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
         cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
     model = build_hip_model(cfg, sd, cuda)
     nt = meta["n_tiles"]
+    H = cfg.llm_config.hidden_size
     got = np.zeros((P, 2, 34), dtype=np.float32)
+    hr = torch.empty(P * 2, H, dtype=torch.bfloat16, device=cuda)
+    hg = torch.empty(P * 2, H, dtype=torch.bfloat16, device=cuda)
     PB = pairs_per_forward
     for p0 in range(0, P, PB):
         px, ids = [], []
@@ -195,8 +266,112 @@ def _rank_case(cuda, name, pairs_per_forward):
                 px.append(synth.synth_pixel_values(meta["pixel_seed"], 2 * p + j, nt, meta["image_size"]))
                 ids.append(row)
         ids_b, mask = synth.pad_batch(ids)
-        model.forward(torch.cat(px).to(cuda), ids_b.to(cuda), mask.to(cuda))
-        got[p0:p0 + len(px) // 2] = model.last_packed34.float().cpu().numpy().reshape(-1, 2, 34)
+        out = model.forward(torch.cat(px).to(cuda), ids_b.to(cuda), mask.to(cuda))
+        n = len(px)
+        got[p0:p0 + n // 2] = model.last_packed34.float().cpu().numpy().reshape(-1, 2, 34)
+        hr[2 * p0:2 * p0 + n] = out.hidden_state
+        hg[2 * p0:2 * p0 + n] = out.prompt_embedding
+    eng = None
+    eng_name = name.replace("rankset", "rankeng")
+    try:
+        enpz, emeta = load_golden(eng_name)
+    except FileNotFoundError:
+        enpz = None
+    if enpz is not None:
+        w = torch.from_numpy(bits_to_f32(enpz["regression_weight_bits"])).to(torch.bfloat16)
+        head_sd = synth.engineered_head_state_dict(cfg, emeta["weight_seed"], w, enpz["gate_dirs"])
+        # the engineered heads are rebuilt here from the stored factors: they must be the very weights the reference scored
+        assert _head_checksum(head_sd) == emeta["head_weights_sha1"], "engineered head weights differ from the fixture's"
+        res = model.load_state_dict(head_sd, strict=False)
+        assert not res.unexpected_keys
+        eng = np.zeros((P, 2, 34), dtype=np.float32)
+        for r0 in range(0, 2 * P, 256):
+            model.heads_forward(hr[r0:r0 + 256], hg[r0:r0 + 256])
+            blk = model.last_packed34.float().cpu().numpy()
+            eng.reshape(-1, 34)[r0:r0 + blk.shape[0]] = blk
+    del model
+    torch.cuda.empty_cache()
+    _RANK_CACHE[name] = dict(meta=meta, got=got, eng=eng)
+    return _RANK_CACHE[name]
+
+
+def test_rank_agreement_c1(cuda):
+    """512 pairs at MJ-VIDEO-2B dims, 8 frames @224 (BASELINE.json configs[0] shape), default synthetic heads: the
+    noise-model test (near-ties included)"""
+    _rank_case(cuda, "rankset_c1", pairs_per_forward=8)
+
+
+def test_rank_agreement_c2(cuda):
+    """Pairs at the headline shape (8 frames @448, N = 2186, BASELINE.json configs[1]), default synthetic heads; the set is
+    smaller because every pair costs the reference about a minute of CPU time."""
+    _rank_case(cuda, "rankset_c2", pairs_per_forward=4)
+
+
+def test_rank_agreement_engineered_c1(cuda):
+    _rank_case_engineered(cuda, "rankset_c1", pairs_per_forward=8)
+
+
+def test_rank_agreement_engineered_c2(cuda):
+    _rank_case_engineered(cuda, "rankset_c2", pairs_per_forward=4)
+
+
+def _rank_case_engineered(cuda, name, pairs_per_forward):
+    """north_star: >= 0.999 rank agreement with the reference on a fixed synthetic set - on the WHOLE set.
+    tests/golden/rankeng_*.npz is the rank set re-scored by the reference's own head code under heads that are fit to the
+    backbone the way trained heads are (make_golden.gen_rankset_eng): score differences between videos are two orders of
+    magnitude above the reference's bf16 noise, and every stored pair is decisive by construction (margin > 12 x the
+    rms bf16-vs-fp32 deviation of these very scores).  Asserted on all kept pairs / all their scores:
+      pairwise preference agreement >= 0.999, Spearman rho >= 0.999, good/bad flag agreement >= 0.999 away from zero,
+      rms deviation <= 2 x the reference's own, and prefer_Acc / Acc of the eval protocol (eval_genai_mjvideo.py:142-165,
+      vote types assigned by pair index) equal to the counts the reference's bookkeeping code produced from its scores."""
+    from scipy.stats import spearmanr
+    from mj_video_amd import harness
+    run = _rank_run(cuda, name, pairs_per_forward)
+    if run["eng"] is None:
+        pytest.skip(f"{name.replace('rankset', 'rankeng')} fixture not generated")
+    enpz, emeta = load_golden(name.replace("rankset", "rankeng"))
+    ref, keep, got = enpz["ref_bf16"], enpz["keep"], run["eng"]
+    P = ref.shape[0]
+    f32, idx32 = enpz["ref_fp32"], enpz["fp32_pairs"]
+    noise = (ref[idx32][..., 0] - f32[..., 0]).ravel()
+    noise_rms = float(np.sqrt((noise ** 2).mean()))
+    d = (got[..., 0] - ref[..., 0]).ravel()
+    spread = float(ref[..., 0].std())
+    print(f"{name} engineered: pairs kept {int(keep.sum())}/{P}; score spread {spread:.4f}; reference bf16-vs-fp32 rms {noise_rms:.5f}; "
+          f"|hip - ref| rms {np.sqrt((d ** 2).mean()):.5f} max {np.abs(d).max():.5f}")
+    assert keep.sum() >= 0.85 * P
+    assert np.sqrt((d ** 2).mean()) <= 2.0 * noise_rms + 1e-3
+    agree = np.sign(got[:, 0, 0] - got[:, 1, 0]) == np.sign(ref[:, 0, 0] - ref[:, 1, 0])
+    print(f"preference agreement on the kept pairs {agree[keep].mean():.5f} ({int((~agree[keep]).sum())} flips), on all pairs {agree.mean():.5f}")
+    assert agree[keep].mean() >= 0.999
+    rho = spearmanr(got[keep][..., 0].ravel(), ref[keep][..., 0].ravel()).correlation
+    rho_all = spearmanr(got[..., 0].ravel(), ref[..., 0].ravel()).correlation
+    print(f"spearman rho over the kept pairs' scores {rho:.6f}, over all {2 * P} scores {rho_all:.6f}")
+    assert rho >= 0.999 and rho_all >= 0.999
+    far = np.abs(ref[..., 0]) > 12 * noise_rms
+    assert ((got[..., 0] > 0) == (ref[..., 0] > 0))[far].mean() >= 0.999
+    # eval protocol on the kept pairs: same counts as the reference's own bookkeeping code gave for its own scores
+    cyc = ["leftvote", "rightvote", "tievote", "bothbad_vote"]
+    counts = harness.evaluate_votes((cyc[i % 4], float(got[i, 0, 0]), float(got[i, 1, 0])) for i in range(P) if keep[i])
+    exp = emeta["accuracy_on_kept_pairs"]
+    print(f"prefer_Acc {counts.prefer_acc:.4f} Acc {counts.acc:.4f}; reference counts {exp}")
+    assert (counts.prefer_truth, counts.prefer_total, counts.truth, counts.total) == \
+        (exp["prefer_truth"], exp["prefer_total"], exp["truth"], exp["total"])
+
+
+def _rank_case(cuda, name, pairs_per_forward):
+    """Fixed synthetic set of pairs scored by the reference under the DEFAULT synthetic heads (random rows: the
+    reference's own bf16 noise is ~7 % of the score spread, so this set has near-ties; it is the noise-model test, the
+    whole-set >= 0.999 criterion is asserted on the engineered set): the HIP scores must (1) deviate from the reference no
+    more than the reference deviates from its own fp32 run, (2) give the same pairwise preference on >= 0.999 of the
+    decisive pairs (margin > 12 x the reference's noise rms) and on no fewer of ALL pairs than the reference's noise
+    predicts, (3) the same good/bad flag, (4) rank mutually separated scores identically; near-ties are reported, not hidden."""
+    run = _rank_run(cuda, name, pairs_per_forward)
+    npz, meta = load_golden(name)
+    ref = npz["ref_bf16"]
+    ref32 = npz["ref_fp32"]
+    P = ref.shape[0]
+    got = run["got"]
     ref = ref[:P]
     f32 = ref32[:P]
     have32 = ~np.isnan(f32[:, 0, 0])
@@ -388,3 +563,213 @@ def test_eval_driver_protocol(cuda):
     assert (counts.prefer_truth, counts.prefer_total, counts.truth, counts.total) == \
         (ref.prefer_truth, ref.prefer_total, ref.truth, ref.total)
     assert counts.total == 5 and counts.prefer_total == 3
+
+
+def _small_backbone_2b_heads(cuda, image_size=224):
+    """MJ-VIDEO-2B head dimensions on a one-layer backbone (the backbone is never run by heads_forward)"""
+    from mj_video_amd import synth
+    from mj_video_amd.modeling import InternVLChatRewardModeling
+    cfg = make_cfg("2b", image_size)
+    cfg.vision_config.num_hidden_layers = 1
+    cfg.llm_config.num_hidden_layers = 1
+    cfg.llm_config.vocab_size = 128
+    model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16)
+    for prm in model.parameters():
+        prm.data.zero_()
+    return cfg, model
+
+
+def test_reward_heads_kernel_against_oracle(cuda):
+    """reward_heads kernel + the gating GEMMs in isolation (heads.hip; moe_reward.py:239-297): given the SAME two hidden
+    rows per sample, every head output against the oracle's head math (proven bit-identical to the reference's own head
+    code by make_golden.gen_rankhid / gen_rankset_eng).  bf16 fields: <= 2 ulps (fp32 accumulation order of the matvecs
+    and of the three 1024-wide gating layers differs; each layer boundary is one bf16 rounding) or 1e-3 absolute where a
+    value sits next to zero; the fp32 score / aspect_scores: 1 % of the magnitude + 2e-3."""
+    from mj_video_amd import synth
+    from oracle import ref_cpu
+    from util import bf16_ulps
+    cfg, model = _small_backbone_2b_heads(cuda)
+    head_sd = synth.synth_head_state_dict(cfg, seed=5)
+    assert not model.load_state_dict(head_sd, strict=False).unexpected_keys
+    model = model.to(cuda).eval()
+    g = torch.Generator().manual_seed(11)
+    B, H = 7, cfg.llm_config.hidden_size
+    h_r = (torch.randn(B, H, generator=g) * 1.1).to(torch.bfloat16)
+    h_g = (torch.randn(B, H, generator=g) * 0.9).to(torch.bfloat16)
+    out = model.heads_forward(h_r.to(cuda), h_g.to(cuda))
+    torch.cuda.synchronize()
+    ref = ref_cpu.reward_heads(head_sd, cfg, h_r, h_g)
+    worst = {}
+    for f in FIELDS:
+        got, exp = getattr(out, f).float().cpu(), ref[f].float()
+        assert got.shape == exp.shape, (f, got.shape, exp.shape)
+        if getattr(out, f).dtype == torch.bfloat16:
+            ul = bf16_ulps(got, exp)
+            ok = (ul <= 2) | ((got - exp).abs() <= 1e-3)
+            worst[f] = int(ul.max())
+            assert ok.all(), (f, int(ul.max()), float((got - exp).abs().max()))
+        else:
+            err = (got - exp).abs()
+            worst[f] = float(err.max())
+            assert (err <= 0.01 * exp.abs() + 2e-3).all(), (f, float(err.max()))
+    assert torch.equal(out.hidden_state.cpu(), h_r) and torch.equal(out.prompt_embedding.cpu(), h_g)
+    print("heads vs oracle, worst (ulps for bf16 fields, abs for fp32):", worst)
+
+
+def _c2_pairs(cuda, n_pairs):
+    """model + inputs of the first n_pairs pairs of the rank set at the headline shape (8 frames @448, N = 2186)"""
+    from mj_video_amd import synth
+    from mj_video_amd.chat_input import num_image_tokens_per_tile
+    npz, meta = load_golden("rankset_c2")
+    cfg = make_cfg("2b", meta["image_size"])
+    sd = synth.synth_state_dict(cfg, seed=meta["weight_seed"], lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
+        cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
+    model = build_hip_model(cfg, sd, cuda)
+    nt = meta["n_tiles"]
+    pairs = []
+    for p in range(n_pairs):
+        row = synth.synth_input_ids(num_image_tokens_per_tile(cfg) * nt, caption_seed=meta["caption_seed_base"] + p)
+        pairs.append((row, [synth.synth_pixel_values(meta["pixel_seed"], 2 * p + j, nt, meta["image_size"]) for j in range(2)]))
+    return model, cfg, npz, meta, pairs
+
+
+def _score_pairs(model, cuda, pairs):
+    from mj_video_amd import synth
+    px, ids = [], []
+    for row, vids in pairs:
+        px += vids
+        ids += [row, row]
+    ids_b, mask = synth.pad_batch(ids)
+    model.forward(torch.cat(px).to(cuda), ids_b.to(cuda), mask.to(cuda))
+    return model.last_packed34.float().reshape(-1, 2, 34)
+
+
+def test_c3_shard_of_16_videos_and_rccl_allgather(cuda):
+    """BASELINE.json configs[2]: 64 pairs over 8 GPUs = 8 pairs = 16 videos per GPU.  (a) one rank's shard in ONE
+    packed forward (M = 131 200 ViT rows, 34 976 LLM rows) against the reference's scores of those 16 videos, within the
+    bounds the 4-pair batches of the rank-set test meet; (b) the N > 1 code path of bench.py / parallel.score_pairs_dp on
+    the RCCL backend with world_size 1: the all_gather_into_tensor of the [pairs, 2, 34] block returns the shard unchanged."""
+    import os
+    import torch.distributed as dist
+    from mj_video_amd import parallel
+    model, cfg, npz, meta, pairs = _c2_pairs(cuda, 8)
+    got = _score_pairs(model, cuda, pairs).cpu().numpy()
+    ref = npz["ref_bf16"][:8]
+    assert np.isfinite(got).all()
+    d = np.abs(got[..., 0] - ref[..., 0])
+    noise_rms = pooled_noise_rms("score")
+    print(f"16-video shard: |hip - ref| score rms {np.sqrt((d ** 2).mean()):.4f} max {d.max():.4f}; reference noise rms {noise_rms:.4f}")
+    assert np.sqrt((d ** 2).mean()) <= 2.0 * noise_rms + ATOL_FLOOR
+    assert d.max() <= TOL_FACTOR * pooled_noise_floor("score") + ATOL_FLOOR
+    # the same videos in two 8-video forwards: equal up to fp32 summation order (tile / split-K choice follows M)
+    two = torch.cat([_score_pairs(model, cuda, pairs[:4]), _score_pairs(model, cuda, pairs[4:])]).cpu().numpy()
+    assert np.abs(two[..., 0] - got[..., 0]).max() <= TOL_FACTOR * pooled_noise_floor("score") + ATOL_FLOOR
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        calls = []
+
+        def score_fn(local):
+            calls.append(len(local))
+            return torch.cat([_score_pairs(model, cuda, local[i:i + 4]) for i in range(0, len(local), 4)])
+
+        full = parallel.score_pairs_dp(score_fn, pairs, device=cuda)
+        assert calls == [8] and full.shape == (8, 2, 34) and full.is_cuda
+        assert torch.equal(full.cpu(), torch.from_numpy(two))
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_c4lite_against_golden(cuda):
+    """BASELINE.json configs[3] (16 frames x dynamic tiles, long-context image tokens) at the largest size the eager
+    reference could run: 48 tiles, N = 12 426 tokens in ONE sequence (tests/golden/c4lite.npz, reference bf16 only).
+    Hidden rows within LAYER_TOL of the reference; head outputs within the pooled noise bounds of the 2 186-token
+    fixtures (no fp32 run exists at this size)."""
+    from mj_video_amd import synth
+    try:
+        npz, meta = load_golden("c4lite")
+    except FileNotFoundError:
+        pytest.skip("c4lite fixture not generated")
+    cfg = make_cfg("2b", meta["image_size"])
+    sd = synth.synth_state_dict(cfg, seed=meta["weight_seed"], lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
+        cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
+    model = build_hip_model(cfg, sd, cuda)
+    vids = [dict(video_idx=0, n_tiles=meta["n_tiles"], caption_seed=meta["caption_seed"])]
+    px, ids, mask, _ = case_inputs(cfg, vids, meta["pixel_seed"], meta["image_size"])
+    assert ids.shape[1] == meta["seq_len"]
+    out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+    torch.cuda.synchronize()
+    for f in FIELDS:
+        got, ref = getattr(out, f)[0].float().cpu().numpy(), npz[f"v0/{f}"][0]
+        assert np.isfinite(got).all(), f
+        if f in ("hidden_state", "prompt_embedding"):
+            e = rel_l2(got, ref)
+            print(f"c4lite {f}: relative L2 {e:.4f}")
+            assert e < LAYER_TOL["llm"], (f, e)
+            continue
+        tol = TOL_FACTOR * pooled_noise_floor(f) + ATOL_FLOOR if f in _PACKED34 else \
+            TOL_FACTOR * max(noise_floor(*_c2_noise(), f), 1e-3) + ATOL_FLOOR
+        d = float(np.abs(got - ref).max())
+        print(f"c4lite {f}: max|d|={d:.3e} tol={tol:.3e}")
+        assert d <= tol, (f, d, tol)
+    again = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+    for f in FIELDS:
+        assert torch.equal(getattr(out, f), getattr(again, f)), f
+
+
+def _c2_noise():
+    npz, meta = load_golden("full_c2")
+    return npz, [f"v{v['video_idx']}" for v in meta["videos"] if f"v{v['video_idx']}/fp32/score" in npz.files]
+
+
+def test_c4_full_112_tiles_end_to_end(cuda):
+    """BASELINE.json configs[3] at full size: 16 frames x 7 tiles = 112 tiles, N = 28 810 tokens in one sequence (the eager
+    reference cannot run it: 26.6 GB of scores + a 53 GB fp32 copy per layer).  The whole forward is finite and bit-
+    deterministic, and the first decoder layer's causal GQA attention - on the q / k / v the real forward produced - agrees
+    with a chunked fp32 evaluation with the reference's score rounding (modeling_internlm2.py:383-411)."""
+    from mj_video_amd import synth
+    cfg = make_cfg("2b", 448)
+    sd = synth.synth_state_dict(cfg, seed=0, lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
+        cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
+    model = build_hip_model(cfg, sd, cuda)
+    vids = [dict(video_idx=0, n_tiles=112, caption_seed=5)]
+    px, ids, mask, _ = case_inputs(cfg, vids, 601, 448)
+    N = ids.shape[1]
+    assert N == 112 * 256 + 138
+    px, ids, mask = px.to(cuda), ids.to(cuda), mask.to(cuda)
+    a = model.forward(px, ids, mask)
+    b = model.forward(px, ids, mask)
+    torch.cuda.synchronize()
+    for f in FIELDS:
+        assert torch.isfinite(getattr(a, f).float()).all(), f
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    model.debug_probes = {}
+    c = model.forward(px, ids, mask)     # untrimmed last layer, every layer's state cloned
+    torch.cuda.synchronize()
+    pr = model.debug_probes["llm_attn0"]
+    model.debug_probes = None
+    assert abs(c.score.item() - a.score.item()) <= TOL_FACTOR * pooled_noise_floor("score") + ATOL_FLOOR
+    q, k, v, o = pr["q"].float(), pr["k"].float(), pr["v"].float(), pr["out"].float()
+    D, KV = 128, pr["kv_heads"]
+    G = q.shape[1] // (KV * D)
+    rows = torch.cat([torch.arange(0, 64), torch.arange(N // 2, N // 2 + 96), torch.arange(N - 96, N)]).to(cuda)
+    scale = D ** -0.5
+    for head in (0, G * KV - 1):
+        kvh = head // G
+        kh = k[:, kvh * D:(kvh + 1) * D]
+        vh = v[:, kvh * (G + 2) * D:kvh * (G + 2) * D + D] if v.shape[1] != KV * D else v[:, kvh * D:(kvh + 1) * D]
+        sc = q[rows, head * D:(head + 1) * D] @ kh.t()
+        sc = (sc.to(torch.bfloat16).float() * scale).to(torch.bfloat16).float()
+        sc = sc.masked_fill(torch.arange(N, device=cuda)[None, :] > rows[:, None], float("-inf"))
+        ref = (torch.softmax(sc, -1).to(torch.bfloat16).float() @ vh).to(torch.bfloat16).float()
+        got = o[rows, head * D:(head + 1) * D]
+        rel = ((got - ref).norm() / ref.norm()).item()
+        print(f"C4 layer-0 attention, head {head}: relative L2 vs chunked fp32 {rel:.2e}")
+        assert rel < 6e-3 and (got - ref).abs().max().item() < 0.03
