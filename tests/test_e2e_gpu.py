@@ -518,11 +518,24 @@ def test_collated_batch_layout(cuda):
         ids, mask = synth.pad_batch([synth.synth_input_ids(per, 20 + b, n_caption=32 - 3 * b * i) for b in range(B)], length=per + 150)
         batch[f"video_{i}_input_ids"], batch[f"video_{i}_attention_mask"] = ids, mask
     o0, o1 = harness.score_collated_batch(model, batch)
+    from oracle import ref_cpu
+    tiny_npz, tiny_meta = load_golden("tiny")
+    names = [c["name"] for c in tiny_meta["cases"]]
+    sd = synth.synth_state_dict(cfg, seed=9, dtype=torch.float32)
+    sd_bf = {k: v.to(torch.bfloat16) for k, v in sd.items()}
     for i, o in ((0, o0), (1, o1)):
         ref = model.forward(batch[f"video_{i}_pixel_values"].reshape(-1, 3, 56, 56).to(cuda), batch[f"video_{i}_input_ids"].to(cuda),
                             batch[f"video_{i}_attention_mask"].to(cuda))
         for f in FIELDS:
             assert torch.equal(getattr(o, f), getattr(ref, f)), (i, f)
+        # ... and against the ORACLE on the collated (right-padded, batch-3) layout itself
+        orc = ref_cpu.reward_forward(sd_bf, cfg, batch[f"video_{i}_pixel_values"].reshape(-1, 3, 56, 56),
+                                     batch[f"video_{i}_input_ids"], batch[f"video_{i}_attention_mask"],
+                                     synth.IMG_CONTEXT_ID, synth.PAD_ID)
+        for f in ("score", "aspect_scores", "rewards", "aspect_gating_output", "aspect_weights", "criteria_gating_output"):
+            tol = TOL_FACTOR * noise_floor(tiny_npz, names, f) + ATOL_FLOOR
+            dlt = float((getattr(o, f).float().cpu() - orc[f].float()).abs().max())
+            assert dlt <= tol, (i, f, dlt, tol)
 
 
 def test_eval_driver_protocol(cuda):
