@@ -123,8 +123,8 @@ def main():
                     help="sample groups scored concurrently on separate HIP streams (2-3 streams: +1-2 %% pairs/s, but the "
                          "per-kernel event durations then include time shared with the other stream's kernel)")
     ap.add_argument("--gemm-code", type=int, action="append", default=[],
-                    help="A/B switches of the GEMM library (mjv_gemm_set_tile codes, e.g. 4000 = no split-K, 6000 = tails in "
-                         "their own launch); not for reported numbers")
+                    help="A/B switches of the GEMM library (mjv_gemm_set_tile codes, e.g. 4000 = no split-K, 6000 = no skinny "
+                         "kernel); not for reported numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()

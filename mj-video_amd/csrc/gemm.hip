@@ -319,6 +319,114 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p) {
 }
 }  // namespace t128
 
+// ============================================================================================ 64 x 32 (skinny M)
+// Small-M problems: the rows peeled off an under-filled last round of the 256^2 kernel (M = 64 in the vision tower, 80
+// for w1|w3), the batch-sized gating layers.  Such a launch is pure latency - a chain of K / 64 dependent LDS fills on
+// the few CUs it occupies, each fill bounded by one CU's L2 -> LDS rate - so the tile is cut small in N (32 weight rows:
+// 12 KiB per K-tile instead of 32) to put the chain on many CUs and shorten every link, and two K-tiles of LDS-DMA stay
+// in flight (three buffers, one barrier per K-tile, counted vmcnt).  Same operand layout, swizzle, fragment maps and
+// epilogue code as the 128^2 kernel; 4 waves, wave w owns activation rows 16 w .. 16 w + 15 of the tile and all 32
+// weight rows (so a SiLU gate / up pair sits in one lane).
+namespace t64 {
+constexpr int BM = 64, BK = 64;
+constexpr int A_BYTES = BM * BK * 2;
+constexpr int NBUF = 3;
+template <int NJ>
+struct Cfg {   // NJ 16-row weight fragments per tile: BN = 32 (skinny M <= 128) or 128 (tails of ~1000 rows)
+  static constexpr int BN = 16 * NJ;
+  static constexpr int W_BYTES = BN * BK * 2;
+  static constexpr int TILE_BYTES = A_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = NBUF * TILE_BYTES;
+  static constexpr int W_PIECES = BN / 8 / 4;        // 1-KiB DMA pieces of the weight tile per wave
+  static constexpr int DMA_PER_TILE = 2 + W_PIECES;  // LDS-DMA instructions a wave issues per K-tile
+};
+
+template <int NJ>
+MJV_DEV void stage(const GemmArgs& p, int m0, int n0, int k0, char* buf, int wave, int lane) {
+  using C = Cfg<NJ>;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {   // activation rows: 8 pieces of 8 rows, two per wave
+    const int piece = wave * 2 + i;
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    int gr = m0 + r;
+    gr = gr < p.M - 1 ? gr : p.M - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + (long)gr * p.lda + k0 + c * 8),
+                                     (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < C::W_PIECES; ++i) {   // weight rows
+    const int piece = wave * C::W_PIECES + i;
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    int gr = n0 + r;
+    gr = gr < p.N - 1 ? gr : p.N - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.W + (long)gr * p.ldw + k0 + c * 8),
+                                     (__attribute__((address_space(3))) void*)(buf + A_BYTES + piece * 1024), 16, 0, 0);
+  }
+}
+
+template <int EPI, int NJ>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+  using C = Cfg<NJ>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int tm = (int)blockIdx.x % p.tiles_m, tn = (int)blockIdx.x / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * C::BN;
+  const int nk = p.K / BK;
+  f32x4 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage<NJ>(p, m0, n0, 0, smem, wave, lane);
+  if (nk > 1) stage<NJ>(p, m0, n0, BK, smem + C::TILE_BYTES, wave, lane);
+  for (int t = 0; t < nk; ++t) {
+    // all but the youngest K-tile's LDS-DMA of this wave must have landed
+    if (t + 1 < nk) {
+      if constexpr (C::DMA_PER_TILE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // K-tile t visible to every wave; buffer (t + 2) % 3 (read in iteration t - 1) is free
+    if (t + 2 < nk) stage<NJ>(p, m0, n0, (t + 2) * BK, smem + ((t + 2) % NBUF) * C::TILE_BYTES, wave, lane);
+    const char* As = smem + (t % NBUF) * C::TILE_BYTES;
+    const char* Ws = As + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int g = kk * 4 + l4;
+      const int ra = wave * 16 + l15;
+      const bf16x8 af = *(const bf16x8*)(As + ra * 128 + ((g ^ (ra & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int rw = j * 16 + l15;
+        const bf16x8 wf = *(const bf16x8*)(Ws + rw * 128 + ((g ^ (rw & 7)) << 4));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  const int mrel = m0 + wave * 16 + l15;
+  if (mrel >= p.M) return;
+  const int m = p.m_base + mrel;
+  const long orow = out_row_of(p, m);
+  if constexpr (EPI == MJV_EPI_SILU_MUL) {
+#pragma unroll
+    for (int j = 0; j < NJ; j += 2) {
+      const int n = n0 + j * 16 + l4 * 4;
+      if (n < p.N) store_silu(p, acc[j], acc[j + 1], orow, n0 / 2 + (j / 2) * 16 + l4 * 4);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + j * 16 + l4 * 4;
+      if (n < p.N) store_frag<EPI>(p, acc[j], m, orow, n);
+    }
+  }
+}
+}  // namespace t64
+
 // ============================================================================================ 256 x 256
 namespace t256 {
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -611,12 +719,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
 thread_local int g_num_cus = 256;   // CUs of the device of the call in flight (mjv_device_cus), set in mjv_gemm_bf16
 int g_gm = 8;
+int g_skinny_max_m = 128;   // problems with at most this many rows run on the 64 x 32 kernel (tile codes 6000 + m; 6000 = off)
 int g_split_max = 8;  // cap on the slices per tile (tile codes 4100 + cap, experiments)
 int g_split_k = 1;  // 1 = split-K for under-filled 128-tile launches when the caller gives a workspace (tile codes 4001 / 4000)
 int g_variant = 0;  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
 
 template <int EPI>
-int launch(GemmArgs a, hipStream_t s, bool big) {
+int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
+  if (skinny) {
+    // (a 64 x 128 tile of the same kernel for the ~1100-row tails of the language tower measured 8 % slower than the
+    // 128 x 128 kernel with split-K: 3.67 vs 3.30 ms per step on the residual GEMMs; only NJ = 2 is instantiated)
+    a.tiles_m = (a.M + t64::BM - 1) / t64::BM;
+    a.tiles_n = (a.N + 31) / 32;
+    hipLaunchKernelGGL((t64::gemm_skinny_kernel<EPI, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), t64::Cfg<2>::LDS_BYTES, s, a);
+    return mjv_check_launch("gemm_bf16");
+  }
   // the dynamic-LDS limit is a per-device function attribute: set it once on every device this instantiation runs on
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
@@ -662,6 +779,10 @@ extern "C" int mjv_gemm_set_tile(int32_t tile) {
     g_split_max = tile - 4100;
     return MJV_OK;
   }
+  if (tile >= 6000 && tile <= 6512) {  // 6000 + m: largest M of the skinny kernel (6000 switches it off; A/B measurements)
+    g_skinny_max_m = tile - 6000;
+    return MJV_OK;
+  }
   if (tile == 4000 || tile == 4001) {  // split-K of under-filled 128-tile launches off / on (A/B measurements)
     g_split_k = tile - 4000;
     return MJV_OK;
@@ -675,8 +796,8 @@ extern "C" int mjv_gemm_set_tile(int32_t tile) {
     g_force_tile = 0;
     return MJV_OK;
   }
-  if (tile != 0 && tile != 128 && tile != 256) {
-    mjv_set_error("gemm_set_tile: %d not in {0,128,256}", tile);
+  if (tile != 0 && tile != 64 && tile != 128 && tile != 256) {
+    mjv_set_error("gemm_set_tile: %d not in {0,64,128,256}", tile);
     return MJV_E_ARG;
   }
   g_force_tile = tile;
@@ -755,16 +876,21 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
     g.split = sp;
     g.ws = (float*)d->workspace;
   };
+  static const char* const tags64[] = {"gemm64_bias", "gemm64_bias_gelu", "gemm64_bias_relu", "gemm64_scale_res",
+                                       "gemm64_silu_mul"};
   auto run = [&](GemmArgs g, bool use_big) -> int {
-    if (!use_big) plan_split(g);
+    // skinny problems (peeled tails of a few dozen rows, batch-sized head layers): the 64 x 32 kernel
+    const bool skinny = !use_big && (g_force_tile ? g_force_tile == 64 : g.M <= g_skinny_max_m);
+    if (!use_big && !skinny) plan_split(g);
     const double frac = (double)g.M / (double)d->M;
-    MjvProfScope ps(use_big ? tags256[d->epilogue] : tags128[d->epilogue], s, flops * frac, bytes * frac);
+    MjvProfScope ps(use_big ? tags256[d->epilogue] : skinny ? tags64[d->epilogue] : tags128[d->epilogue], s, flops * frac,
+                    bytes * frac);
     switch (d->epilogue) {
-      case MJV_EPI_BIAS: return launch<MJV_EPI_BIAS>(g, s, use_big);
-      case MJV_EPI_BIAS_GELU: return launch<MJV_EPI_BIAS_GELU>(g, s, use_big);
-      case MJV_EPI_BIAS_RELU: return launch<MJV_EPI_BIAS_RELU>(g, s, use_big);
-      case MJV_EPI_SCALE_RES: return launch<MJV_EPI_SCALE_RES>(g, s, use_big);
-      default: return launch<MJV_EPI_SILU_MUL>(g, s, use_big);
+      case MJV_EPI_BIAS: return launch<MJV_EPI_BIAS>(g, s, use_big, skinny);
+      case MJV_EPI_BIAS_GELU: return launch<MJV_EPI_BIAS_GELU>(g, s, use_big, skinny);
+      case MJV_EPI_BIAS_RELU: return launch<MJV_EPI_BIAS_RELU>(g, s, use_big, skinny);
+      case MJV_EPI_SCALE_RES: return launch<MJV_EPI_SCALE_RES>(g, s, use_big, skinny);
+      default: return launch<MJV_EPI_SILU_MUL>(g, s, use_big, skinny);
     }
   };
   if (m_main == d->M) return run(a, big);

@@ -34,9 +34,10 @@ def assert_close_bf16(out, ref, max_ulps, frac_exact=0.0, atol=0.0, what=""):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[128, 256])
+@pytest.fixture(params=[64, 128, 256])
 def tile(request, cuda):
-    """run every GEMM test on both tile kernels (the automatic choice would hide the 256^2 kernel at test sizes)"""
+    """run every GEMM test on all three tile kernels (the automatic choice would hide the 256^2 kernel at test sizes and
+    the 64 x 32 skinny kernel above 128 rows)"""
     from mj_video_amd import ops
     ops.gemm_set_tile(request.param)
     yield request.param
@@ -411,6 +412,22 @@ def test_gemm_tail_peeling_is_invisible(cuda):
     ref2 = ((a2.float() @ w2.float().t()).view(-1, P, 2048) + table[1:].float()).to(BF)
     got = out.view(-1, P + 1, 2048)
     assert torch.equal(got[:, 1:], ref2) and (got[:, 0] == 0).all()
+    # the vision tower's shape: M = 64 x 1025 = 256 x 256 + 64 -> the 64 ragged rows go to the 64 x 32 skinny kernel
+    M3, N3 = 65600, 1024                 # 257 x 4 = 1028 tiles -> 4 full rounds + 4
+    a3 = torch.randint(-1, 2, (M3, K), generator=g).float().to(BF).to(cuda)
+    w3 = torch.randint(-1, 2, (N3, K), generator=g).float().to(BF).to(cuda)
+    b3 = torch.randint(-2, 3, (N3,), generator=g).float().to(BF).to(cuda)
+    ls3 = torch.randint(1, 3, (N3,), generator=g).float().to(BF).to(cuda)
+    r3 = torch.randint(-8, 9, (M3, N3), generator=g).float().to(BF).to(cuda)
+    x3 = r3.clone()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    ops.gemm(a3, w3, x3, ops.EPI_SCALE_RES, bias=b3, scale=ls3, res=x3)
+    ops.prof_enable(False)
+    tags = ops.prof_results()
+    assert tags["gemm256_scale_res"]["launches"] == 1 and tags["gemm64_scale_res"]["launches"] == 1, tags
+    ref3 = (r3.float() + ((a3.float() @ w3.float().t() + b3.float()).to(BF).float() * ls3.float()).to(BF).float()).to(BF)
+    assert torch.equal(x3, ref3)
 
 
 def test_attention_long_context_c4(cuda, attn_variant):
