@@ -486,7 +486,10 @@ MJV_DEV void stage_half(const StagePtrs& sp, int t, int nk, char* smem, int wave
 
 // VAR 0: production.  VAR 3 / 4: timing experiments (no epilogue / no global stores) used to attribute the epilogue's
 // cost; selected with mjv_gemm_set_tile(1000 + VAR), never by the automatic path.
-// Tried and rejected on this structure (A/B in one process, tools/gemm_bench.py; code in git history): issuing the
+// Tried and rejected on this structure (A/B in one process, tools/gemm_bench.py; code in git history): delaying every
+// other first-round workgroup by half a tile time so that the CUs' epilogue store bursts stop colliding (round 2:
+// -1 ... -20 % on every model shape - the delay is never recovered, so the lockstep burst is not what the epilogue waits
+// for); issuing the
 // LDS-DMA in the middle of the MFMA segment instead of the load segment (-5 %); a persistent one-workgroup-per-CU form
 // that prefetches the next tile's first K-tile under the epilogue (neutral: s_waitcnt vmcnt is in-order, the first DMA
 // wait also waits for the epilogue's stores); a role-split persistent form where 4 waves issue all DMA and the other 4
@@ -801,6 +804,7 @@ extern "C" int mjv_gemm_set_tile(int32_t tile) {
     return MJV_E_ARG;
   }
   g_force_tile = tile;
+  if (tile == 0) g_variant = 0;   // "automatic" also leaves the experimental kernel variants
   return MJV_OK;
 }
 
