@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MJV_ABI_VERSION 2
+#define MJV_ABI_VERSION 3
 
 enum {
   MJV_OK = 0,
@@ -56,8 +56,14 @@ enum mjv_epilogue {
   MJV_EPI_BIAS_GELU = 1,  /* C = bf16(gelu_erf(bf16(acc + bias)))       (F.gelu on the bf16 Linear)  */
   MJV_EPI_BIAS_RELU = 2,  /* C = bf16(max(acc + bias, 0))                                           */
   MJV_EPI_SCALE_RES = 3,  /* v = bf16(acc + bias); if scale: v = bf16(v * scale[n]); C = bf16(res + v) */
-  MJV_EPI_SILU_MUL = 4    /* W rows interleaved [16 x w1 | 16 x w3]...; C[M,N/2] =
+  MJV_EPI_SILU_MUL = 4,   /* W rows interleaved [16 x w1 | 16 x w3]...; C[M,N/2] =
                              bf16( bf16(silu(bf16(acc_w1))) * bf16(acc_w3) )   (modeling_internlm2.py:262) */
+  MJV_EPI_ROPE_QKV = 5    /* InternLM2 wqkv (modeling_internlm2.py:359-381): columns are kv groups of (rope_group + 2) heads
+                             of 128 = [q heads of the group | k | v].  v = bf16(acc) goes to C (its own columns, the other
+                             columns of C are left untouched); the q and k heads get the rotary embedding on the bf16 Linear
+                             output, out = bf16(bf16(x cos) + bf16(rotate_half(x) sin)) with cos / sin rows taken at
+                             rope_pos[m], and go de-interleaved to rope_q [M][heads * 128] / rope_k [M][kv_heads * 128].
+                             Needs N % ((rope_group + 2) * 128) == 0, no bias. */
 };
 
 typedef struct mjv_gemm_desc {
@@ -78,6 +84,12 @@ typedef struct mjv_gemm_desc {
                                        flight; lets under-filled launches split K (fp32 partial tiles, summed in a fixed
                                        order: results stay deterministic).  NULL: never split.  mjv_gemm_workspace_bytes() */
   int64_t workspace_bytes;
+  /* MJV_EPI_ROPE_QKV only */
+  const mjv_bf16 *rope_cos, *rope_sin;   /* [positions][128] tables (bf16, modeling_internlm2.py:147-180) */
+  const int32_t* rope_pos;               /* [M] position of every row (device) */
+  mjv_bf16 *rope_q, *rope_k;             /* outputs */
+  int64_t rope_ldq, rope_ldk;
+  int32_t rope_group;                    /* q heads per kv head */
 } mjv_gemm_desc;
 
 /* a workspace of this size is enough for every problem shape (512 partial 128x128 fp32 tiles) */

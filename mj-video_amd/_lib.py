@@ -15,14 +15,14 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libmjv_hip.so")
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_SCALE_RES, EPI_SILU_MUL = range(5)
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_SCALE_RES, EPI_SILU_MUL, EPI_ROPE_QKV = range(6)
 
 
 class MjvLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2  # MJV_ABI_VERSION of include/mjv.h
+ABI_VERSION = 3  # MJV_ABI_VERSION of include/mjv.h
 
 
 class GemmDesc(C.Structure):
@@ -31,7 +31,9 @@ class GemmDesc(C.Structure):
                 ("epilogue", C.c_int32), ("bias", C.c_void_p), ("scale", C.c_void_p), ("res", C.c_void_p),
                 ("ldr", C.c_int64), ("res_mod", C.c_int32), ("res_off", C.c_int32), ("out_group", C.c_int32),
                 ("out_pad", C.c_int32), ("out_rows", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_int64)]
+                ("workspace_bytes", C.c_int64), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("rope_pos", C.c_void_p), ("rope_q", C.c_void_p), ("rope_k", C.c_void_p), ("rope_ldq", C.c_int64),
+                ("rope_ldk", C.c_int64), ("rope_group", C.c_int32)]
 
 
 class AttnDesc(C.Structure):

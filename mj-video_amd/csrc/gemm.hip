@@ -69,6 +69,12 @@ struct GemmArgs {
   int m_base;  // absolute index of row 0 of A (tail launches): output / residual rows are computed from m_base + m
   float* ws;   // split-K: fp32 partial tiles, [tile][slice][fragment][thread] float4 (the accumulators as they sit in registers)
   int split;   // K slices per tile (1 = no split)
+  // MJV_EPI_ROPE_QKV
+  const u16 *rope_cos, *rope_sin;
+  const int* rope_pos;
+  u16 *rope_q, *rope_k;
+  long rope_ldq, rope_ldk;
+  int rope_group;
 };
 
 // x * rcp(1 + e^-x): v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division; the result is rounded to bf16 next, and
@@ -680,6 +686,65 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
       }
     }
+    if constexpr (EPI == MJV_EPI_ROPE_QKV) {
+      // wqkv: the 256-column tile holds two whole 128-wide heads, so a row's rotate_half partner (column d +- 64 of the
+      // same head) is in the staged tile.  q / k heads: out = bf16(bf16(x cos) + bf16(rot sin)) to the de-interleaved q / k
+      // buffers; v heads: copied to their columns of C.  Same three roundings, same operation order as rope_split_kernel.
+      // every row's position first (the accumulators are dead: their registers hold these loads across the barrier), then
+      // the cos / sin rows of HALF the passes at a time, all in flight together - a position -> table-row -> use chain per
+      // pass would put two dependent global-memory latencies on each of the 16 passes of the tile
+      const int gs = (p.rope_group + 2) * 128;        // columns per kv group
+      const int blk_col = c8 & 128;                    // which of the tile's two heads this thread works on
+      const int ncol = n0 + blk_col;                   // first column of that head
+      const int grp = ncol / gs, within = (ncol - grp * gs) >> 7;   // kv group, head slot inside it (uniform per half-row)
+      const int dcol = c8 & 127;                       // column inside the head
+      const bool is_v = within == p.rope_group + 1, is_k = within == p.rope_group;
+      const bool col_ok = n < nlim;
+      int posv[PASSES];
+#pragma unroll
+      for (int it = 0; it < PASSES; ++it) {
+        const int ml = it * ROWS_PER_PASS + ml0;
+        posv[it] = (!is_v && col_ok && m0 + ml < p.M) ? p.rope_pos[(long)p.m_base + m0 + ml] : 0;
+      }
+      __syncthreads();
+      const float sgn = dcol < 64 ? -1.f : 1.f;        // rotate_half: (-x2, x1)
+      constexpr int HALF = PASSES / 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 cs_raw[HALF], sn_raw[HALF];
+        if (!is_v) {
+#pragma unroll
+          for (int i = 0; i < HALF; ++i) {
+            cs_raw[i] = *(const u32x4*)(p.rope_cos + (long)posv[h * HALF + i] * 128 + dcol);
+            sn_raw[i] = *(const u32x4*)(p.rope_sin + (long)posv[h * HALF + i] * 128 + dcol);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+          const int it = h * HALF + i;
+          const int ml = it * ROWS_PER_PASS + ml0;
+          if (m0 + ml >= p.M || !col_ok) continue;
+          const long m = (long)p.m_base + m0 + ml;
+          const u32x4 val = *(const u32x4*)(etile + ml * EPI_PITCH + c8 * 2);
+          if (is_v) {
+            *(u32x4*)(p.C + m * p.ldc + n) = val;
+            continue;
+          }
+          const u32x4 par = *(const u32x4*)(etile + ml * EPI_PITCH + (c8 ^ 64) * 2);
+          float x[8], y[8], cs[8], sn[8], o[8];
+          unpack8(val, x);
+          unpack8(par, y);
+          unpack8(cs_raw[i], cs);
+          unpack8(sn_raw[i], sn);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rbf(x[e] * cs[e]) + rbf((sgn * y[e]) * sn[e]);
+          u16* dst = is_k ? p.rope_k + m * p.rope_ldk + (long)grp * 128 + dcol
+                          : p.rope_q + m * p.rope_ldq + ((long)grp * p.rope_group + within) * 128 + dcol;
+          *(u32x4*)dst = pack8(o);
+        }
+      }
+      return;
+    }
     __syncthreads();
     // plain row mapping (output row == residual row == m) is the common case: keep the integer divisions of the
     // row maps (CLS slot / pos-emb period / <IMG_CONTEXT> scatter) out of it
@@ -822,6 +887,14 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   if (d->epilogue == MJV_EPI_SILU_MUL) {
     MJV_REQUIRE(d->N % 32 == 0 && d->bias == nullptr, "gemm: SILU_MUL needs N %% 32 == 0 and no bias");
   }
+  if (d->epilogue == MJV_EPI_ROPE_QKV) {
+    MJV_REQUIRE(d->rope_cos && d->rope_sin && d->rope_pos && d->rope_q && d->rope_k && d->rope_group > 0,
+                "gemm: ROPE_QKV needs cos / sin / positions / q / k / group");
+    MJV_REQUIRE(d->N % ((d->rope_group + 2) * 128) == 0 && d->bias == nullptr && !d->out_rows && d->out_group <= 0,
+                "gemm: ROPE_QKV needs N %% ((group + 2) * 128) == 0, no bias, plain output rows");
+    MJV_REQUIRE(d->rope_ldq % 8 == 0 && d->rope_ldk % 8 == 0 && ((uintptr_t)d->rope_q | (uintptr_t)d->rope_k |
+                (uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) % 16 == 0, "gemm: ROPE_QKV alignment");
+  }
   GemmArgs a;
   a.A = d->A; a.lda = d->lda; a.W = d->W; a.ldw = d->ldw; a.C = d->C; a.ldc = d->ldc;
   a.M = d->M; a.N = d->N; a.K = d->K;
@@ -833,6 +906,8 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.ws = nullptr;
   a.split = 1;
   a.gm = g_gm;
+  a.rope_cos = d->rope_cos; a.rope_sin = d->rope_sin; a.rope_pos = d->rope_pos; a.rope_q = d->rope_q; a.rope_k = d->rope_k;
+  a.rope_ldq = d->rope_ldq; a.rope_ldk = d->rope_ldk; a.rope_group = d->rope_group;
   a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;
   const bool big = g_force_tile ? g_force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;
@@ -855,10 +930,10 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
     }
   }
   static const char* const tags256[] = {"gemm256_bias", "gemm256_bias_gelu", "gemm256_bias_relu", "gemm256_scale_res",
-                                        "gemm256_silu_mul"};
+                                        "gemm256_silu_mul", "gemm256_rope_qkv"};
   static const char* const tags128[] = {"gemm128_bias", "gemm128_bias_gelu", "gemm128_bias_relu", "gemm128_scale_res",
                                         "gemm128_silu_mul"};
-  if (d->epilogue < 0 || d->epilogue > 4) {
+  if (d->epilogue < 0 || d->epilogue > MJV_EPI_ROPE_QKV) {
     mjv_set_error("gemm: unknown epilogue %d", d->epilogue);
     return MJV_E_ARG;
   }
@@ -887,15 +962,28 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
     const bool skinny = !use_big && (g_force_tile ? g_force_tile == 64 : g.M <= g_skinny_max_m);
     if (!use_big && !skinny) plan_split(g);
     const double frac = (double)g.M / (double)d->M;
-    MjvProfScope ps(use_big ? tags256[d->epilogue] : skinny ? tags64[d->epilogue] : tags128[d->epilogue], s, flops * frac,
-                    bytes * frac);
-    switch (d->epilogue) {
-      case MJV_EPI_BIAS: return launch<MJV_EPI_BIAS>(g, s, use_big, skinny);
-      case MJV_EPI_BIAS_GELU: return launch<MJV_EPI_BIAS_GELU>(g, s, use_big, skinny);
-      case MJV_EPI_BIAS_RELU: return launch<MJV_EPI_BIAS_RELU>(g, s, use_big, skinny);
-      case MJV_EPI_SCALE_RES: return launch<MJV_EPI_SCALE_RES>(g, s, use_big, skinny);
-      default: return launch<MJV_EPI_SILU_MUL>(g, s, use_big, skinny);
+    // the rotary epilogue needs a whole 256-column tile staged in LDS: only the 256^2 kernel has it.  Rows that run on the
+    // smaller kernels (peeled tails, small problems) get the plain Linear into C and the standalone rope_split kernel.
+    const int epi = (d->epilogue == MJV_EPI_ROPE_QKV && !use_big) ? (int)MJV_EPI_BIAS : d->epilogue;
+    int rc;
+    {
+      MjvProfScope ps(use_big ? tags256[epi] : skinny ? tags64[epi] : tags128[epi], s, flops * frac, bytes * frac);
+      switch (epi) {
+        case MJV_EPI_BIAS: rc = launch<MJV_EPI_BIAS>(g, s, use_big, skinny); break;
+        case MJV_EPI_BIAS_GELU: rc = launch<MJV_EPI_BIAS_GELU>(g, s, use_big, skinny); break;
+        case MJV_EPI_BIAS_RELU: rc = launch<MJV_EPI_BIAS_RELU>(g, s, use_big, skinny); break;
+        case MJV_EPI_SCALE_RES: rc = launch<MJV_EPI_SCALE_RES>(g, s, use_big, skinny); break;
+        case MJV_EPI_ROPE_QKV: rc = launch<MJV_EPI_ROPE_QKV>(g, s, true, false); break;
+        default: rc = launch<MJV_EPI_SILU_MUL>(g, s, use_big, skinny); break;
+      }
     }
+    if (rc == MJV_OK && epi != d->epilogue) {
+      const long r0 = g.m_base;
+      rc = mjv_rope_split_bf16(d->C + r0 * d->ldc, d->ldc, d->rope_q + r0 * d->rope_ldq, d->rope_ldq,
+                               d->rope_k + r0 * d->rope_ldk, d->rope_ldk, d->rope_cos, d->rope_sin, d->rope_pos + r0, g.M,
+                               d->N / ((d->rope_group + 2) * 128), d->rope_group, stream);
+    }
+    return rc;
   };
   if (m_main == d->M) return run(a, big);
   GemmArgs head = a;

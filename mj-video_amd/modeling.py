@@ -26,7 +26,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_SCALE_RES, EPI_SILU_MUL, HeadsDesc)
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_ROPE_QKV, EPI_SCALE_RES, EPI_SILU_MUL, HeadsDesc)
 from .chat_input import get_conv_template
 from .configuration import InternVLChatConfig, InternVLChatRewardModelingConfig
 
@@ -593,8 +593,9 @@ class InternVLChatRewardModeling(nn.Module):
         last = len(lm.layers) - 1
         for li, layer in enumerate(lm.layers):
             ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
-            ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_BIAS)
-            ops.rope_split(qkv, q, k, cos, sin, positions, KV, G)
+            # wqkv with the rotary embedding + GQA de-interleave in its epilogue: q / k go (rotated) to their own buffers,
+            # v stays in its columns of qkv (modeling_internlm2.py:359-381)
+            ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_ROPE_QKV, rope=(cos, sin, positions, q, k, G))
             ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, 1, v_head_stride=(G + 2) * hd)
             if self.debug_probes is not None and li == 0:   # operands / result of the first causal attention (parity tests)
                 self.debug_probes["llm_attn0"] = dict(q=q.clone(), k=k.clone(), v=v_view.clone(), out=hn.clone(), kv_heads=KV)

@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_SCALE_RES, EPI_SILU_MUL, AttnDesc, GemmDesc,
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_ROPE_QKV, EPI_SCALE_RES, EPI_SILU_MUL, AttnDesc, GemmDesc,
                    HeadsDesc, check, load_library)
 
 BF16 = torch.bfloat16
@@ -56,8 +56,10 @@ def set_gemm_workspace(ws: Optional[torch.Tensor]) -> None:
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_BIAS,
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, res_mod: int = 0, res_off: int = 0, out_group: int = 0,
-         out_pad: int = 0, out_rows: Optional[torch.Tensor] = None, M: Optional[int] = None) -> torch.Tensor:
-    """out = epilogue(a[M,K] @ w[N,K]^T); 2-D row-contiguous bf16 views (row strides are honoured)."""
+         out_pad: int = 0, out_rows: Optional[torch.Tensor] = None, M: Optional[int] = None,
+         rope: Optional[tuple] = None) -> torch.Tensor:
+    """out = epilogue(a[M,K] @ w[N,K]^T); 2-D row-contiguous bf16 views (row strides are honoured).
+    ``rope`` (EPI_ROPE_QKV only) = (cos, sin, positions, q_out, k_out, group): see include/mjv.h."""
     _chk_bf16(a, w, out, bias, scale, res)
     lib = load_library()
     d = GemmDesc()
@@ -74,6 +76,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     if out_rows is not None:
         assert out_rows.dtype == torch.int32 and out_rows.is_cuda
     d.out_rows = _p(out_rows)
+    if epilogue == EPI_ROPE_QKV:
+        cos, sin, positions, q_out, k_out, group = rope
+        _chk_bf16(cos, sin, q_out, k_out)
+        assert positions.dtype == torch.int32 and positions.is_cuda and positions.numel() >= d.M
+        assert cos.shape[1] == 128 and cos.is_contiguous() and sin.is_contiguous()
+        d.rope_cos, d.rope_sin, d.rope_pos = cos.data_ptr(), sin.data_ptr(), positions.data_ptr()
+        d.rope_q, d.rope_k = q_out.data_ptr(), k_out.data_ptr()
+        d.rope_ldq, d.rope_ldk, d.rope_group = _row_stride(q_out), _row_stride(k_out), group
     if _GEMM_WS is not None and _GEMM_WS.device == a.device:
         d.workspace, d.workspace_bytes = _GEMM_WS.data_ptr(), _GEMM_WS.numel() * _GEMM_WS.element_size()
     check(lib.mjv_gemm_bf16(C.byref(d), _stream(out)), "mjv_gemm_bf16")

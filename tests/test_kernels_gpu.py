@@ -201,6 +201,37 @@ def test_rope_split(cuda):
     assert torch.equal(k.cpu(), kr.reshape(rows, -1))
 
 
+@pytest.mark.parametrize("M", [17488, 2186, 300])
+def test_gemm_rope_qkv_epilogue_equals_gemm_then_rope(cuda, M):
+    """InternLM2 wqkv with RoPE + GQA de-interleave fused into the GEMM epilogue (MJV_EPI_ROPE_QKV) against the two-kernel
+    path it replaces (plain Linear, then rope_split - itself bit-exact against the torch formula, test_rope_split): q, k
+    and the v columns must be bit-identical.  M = 17488 takes the 256^2 kernel + a peeled tail (which falls back to the
+    two-kernel path inside the library), 2186 the 256^2 kernel alone, 300 the small kernels only."""
+    from mj_video_amd import ops
+    H, KV, D, hid = 16, 8, 128, 2048
+    G = H // KV
+    N = (H + 2 * KV) * D
+    a, w = rnd(M, hid, seed=1).to(cuda), rnd(N, hid, std=0.03, seed=2).to(cuda)
+    g = torch.Generator().manual_seed(4)
+    pos = torch.randint(0, 4096, (M,), generator=g).to(torch.int32).to(cuda)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.einsum("i,j->ij", torch.arange(4096).float(), inv)
+    emb = torch.cat((fr, fr), dim=-1)
+    cos, sin = emb.cos().to(BF).to(cuda).contiguous(), emb.sin().to(BF).to(cuda).contiguous()
+    qkv0 = torch.zeros(M, N, dtype=BF, device=cuda)
+    q0, k0 = torch.empty(M, H * D, dtype=BF, device=cuda), torch.empty(M, KV * D, dtype=BF, device=cuda)
+    ops.gemm(a, w, qkv0, ops.EPI_BIAS)
+    ops.rope_split(qkv0, q0, k0, cos, sin, pos, KV, G)
+    qkv1 = torch.zeros(M, N, dtype=BF, device=cuda)
+    q1, k1 = torch.empty(M, H * D, dtype=BF, device=cuda), torch.empty(M, KV * D, dtype=BF, device=cuda)
+    ops.gemm(a, w, qkv1, ops.EPI_ROPE_QKV, rope=(cos, sin, pos, q1, k1, G))
+    torch.cuda.synchronize()
+    assert torch.equal(q0, q1) and torch.equal(k0, k1)
+    v0 = qkv0.view(M, KV, G + 2, D)[:, :, G + 1]
+    v1 = qkv1.view(M, KV, G + 2, D)[:, :, G + 1]
+    assert torch.equal(v0, v1)
+
+
 def test_patchify_cls_embed(cuda):
     from mj_video_amd import ops
     tiles, S, P = 2, 56, 14
