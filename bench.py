@@ -119,13 +119,13 @@ def main():
     ap.add_argument("--pairs", type=int, default=4, help="pairs per GPU per step (BASELINE.json configs[1]: 4)")
     ap.add_argument("--image-size", type=int, default=448)
     ap.add_argument("--frames", type=int, default=8, help="tiles per video (frames x tiles per frame; configs[3]: 16 x 7 = 112)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="sample groups scored concurrently on separate HIP streams (2-3 streams: +1-2 %% pairs/s, but the "
-                         "per-kernel event durations then include time shared with the other stream's kernel)")
     ap.add_argument("--gemm-code", type=int, action="append", default=[],
                     help="A/B switches of the GEMM library (mjv_gemm_set_tile codes, e.g. 4000 = no split-K, 6000 = no skinny "
                          "kernel); not for reported numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the single-video latency section (profiling runs: keeps small-batch launches out of the "
+                         "per-kernel statistics)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -162,7 +162,6 @@ def main():
     model.config.pad_token_id = synth.PAD_ID
     model.model.img_context_token_id = synth.IMG_CONTEXT_ID
     model.eval()
-    model.n_streams = args.streams
     for code in args.gemm_code:
         ops.gemm_set_tile(code)
 
@@ -245,7 +244,6 @@ def main():
             "config": {"workload": f"MJ-VIDEO-2B, batch={args.pairs} pairs per GPU, {F} frames @{S}^2 max_num=1, "
                                    f"N={seq_len} tokens/video, random-init weights, inputs resident in HBM",
                        "pairs_per_gpu_per_step": args.pairs, "global_pairs_per_step": args.pairs * world,
-                       "hip_streams_per_gpu": args.streams,
                        "ids": "fresh id / mask tensors every step (one device->host copy of the ids per forward)",
                        "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
             "frac_of_mfma_roofline": round(value * ALGO_TFLOP_PER_PAIR / (MFMA_BF16_PEAK_TFLOPS * world), 4)
@@ -280,32 +278,9 @@ def main():
                         for k, v in sorted(res.items(), key=lambda kv: -kv[1]["ms"])}
 
             line["roofline"] = roofline(res, args.steps, share_from=res_all)
-            line["roofline"]["note"] = ("events around this kernel's launches on their launch stream inside the timed region "
-                                        "(share_of_kernel_time and the `kernels` table: all kernels, last warm-up step); "
-                                        "with 2 HIP streams kernels of "
-                                        "the two sample groups overlap, so per-launch durations include time shared with "
-                                        "the other stream's kernel (see roofline_isolated)") if args.streams > 1 else \
-                "events around this kernel's launches on the launch stream inside the timed region"
+            line["roofline"]["note"] = "events around this kernel's launches on the launch stream inside the timed region"
             line["kernels"] = table(res_all, 1)
-            if args.streams > 1:
-                # the same step with ONE stream (no co-running kernels): per-kernel durations comparable with rocprofv3
-                model.n_streams = 1
-                step()
-                fence()
-                ops.prof_reset()
-                ops.prof_enable(True)
-                t1 = time.perf_counter()
-                for _ in range(2):
-                    step()
-                fence()
-                iso_ms = 1e3 * (time.perf_counter() - t1) / 2
-                ops.prof_enable(False)
-                iso = ops.prof_results()
-                line["roofline_isolated"] = roofline(iso, 2)
-                line["roofline_isolated"]["ms_per_step_single_stream"] = round(iso_ms, 3)
-                line["kernels_isolated"] = table(iso, 2)
-                model.n_streams = args.streams
-        if world == 1:
+        if world == 1 and not args.no_latency:
             # the reference's real call pattern: ONE video per forward (eval_genai_mjvideo.py:140-141), fresh ids each time
             px1, ids1, mask1 = px[:F].contiguous(), ids[:1].contiguous(), mask[:1].contiguous()
             for _ in range(2):

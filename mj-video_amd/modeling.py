@@ -328,10 +328,6 @@ class InternVLChatRewardModeling(nn.Module):
         self.last_packed34: Optional[torch.Tensor] = None
         self._ws_tag = "g0"
         self._host_cache = None
-        self._streams: List[torch.cuda.Stream] = []
-        # sample groups scored concurrently on separate HIP streams.  1 = everything on the caller's stream (default);
-        # 2-3 overlap one group's GEMM tail rounds with the other group's kernels: +1-2 % at twice the workspace
-        self.n_streams = 1
         self.debug_probes: Optional[Dict[str, torch.Tensor]] = None  # tests set {} to capture per-layer states
 
     # -- construction helpers -------------------------------------------------------------------
@@ -622,10 +618,10 @@ class InternVLChatRewardModeling(nn.Module):
 
     # -- forward ---------------------------------------------------------------------------------
     def _forward_group(self, d, tag: str, pixel_values, input_ids, attention_mask, outs, lo: int, probes_ok: bool):
-        """Scores samples [lo, lo+B) of the batch on the CURRENT stream with its own workspace ``tag``."""
+        """Scores the batch on the CURRENT stream of the model's device (outputs go to rows [lo, lo+B) of ``outs``)."""
         dev = pixel_values.device
         self._ws_tag = tag
-        # split-K scratch of this group's GEMMs (per group = per stream: two streams never share one)
+        # split-K scratch of this forward's GEMMs (private to the stream the forward runs on)
         ops.set_gemm_workspace(self._buf("gemm_ws", 1, ops.gemm_workspace_bytes(), dev, dtype=torch.uint8))
         info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])  # host arrays (see forward)
         B, total = info["B"], info["total"]
@@ -732,24 +728,6 @@ class InternVLChatRewardModeling(nn.Module):
         self.last_packed34 = outs.pop("packed34")
         return CustomOutput(**outs)
 
-    def _split_batch(self, input_ids: np.ndarray, n_tiles: int, groups: int):
-        """[(sample_lo, sample_hi, tile_lo, tile_hi)] - contiguous sample groups with their pixel tiles."""
-        B = input_ids.shape[0]
-        groups = max(1, min(groups, B))
-        if groups == 1:
-            return [(0, B, 0, n_tiles)]
-        ctx = self.model.img_context_token_id
-        per = self.model.num_image_token
-        counts = (input_ids == ctx).sum(axis=1).tolist()
-        tiles = [c // per for c in counts]
-        out, s0, t0 = [], 0, 0
-        for g in range(groups):
-            s1 = (B * (g + 1)) // groups
-            t1 = t0 + sum(tiles[s0:s1])
-            out.append((s0, s1, t0, t1))
-            s0, t0 = s1, t1
-        return out
-
     @torch.no_grad()
     def forward(self, pixel_values: torch.Tensor, input_ids: torch.Tensor = None,
                 attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.Tensor] = None,
@@ -778,39 +756,12 @@ class InternVLChatRewardModeling(nn.Module):
             raise ValueError("Cannot handle batch sizes > 1 if no padding token is defined.")
         outs = self._alloc_outputs(B, dev)
         ids_h, am_h = self._host_ids(input_ids, attention_mask)
-        n_groups = 1 if self.debug_probes is not None else self.n_streams
-        # shared lazily-built tables must exist before the streams fork
-        self._rope_tables(int(input_ids.shape[1]), dev)
-        if pixel_values.shape[-1] % self.config.vision_config.patch_size == 0:
-            self._pos_table(d, pixel_values.shape[-1] // self.config.vision_config.patch_size, dev)
-        groups = self._split_batch(ids_h, pixel_values.shape[0], n_groups)
         try:
             # the model's device becomes the current device for the whole forward (allocations, events, the library's
             # per-device kernel attributes), whatever the caller's current device is: model.cuda(1) works like the reference
             with torch.cuda.device(dev):
-                self._run_groups(d, groups, pixel_values, ids_h, am_h, outs, dev)
+                self._forward_group(d, "g0", pixel_values, ids_h, am_h, outs, 0, True)
         finally:   # the split-K scratch is a process-wide setting of ops: do not leave it behind for other gemm callers
             ops.set_gemm_workspace(None)
         self.last_packed34 = outs.pop("packed34")
         return CustomOutput(**outs)
-
-    def _run_groups(self, d, groups, pixel_values, ids_h, am_h, outs, dev):
-        if len(groups) == 1:
-            self._forward_group(d, "g0", pixel_values, ids_h, am_h, outs, 0, True)
-        else:
-            # independent sample groups on separate HIP streams: one group's GEMM tail / attention overlaps the
-            # other's kernels on otherwise idle CUs; per-sample math is unchanged (packing is per sample)
-            main = torch.cuda.current_stream(dev)
-            while len(self._streams) < len(groups):
-                self._streams.append(torch.cuda.Stream(device=dev))
-            fork = torch.cuda.Event()
-            fork.record(main)
-            for gi, (s0, s1, t0, t1) in enumerate(groups):
-                st = self._streams[gi]
-                st.wait_event(fork)
-                with torch.cuda.stream(st):
-                    self._forward_group(d, f"g{gi}", pixel_values[t0:t1], ids_h[s0:s1],
-                                        None if am_h is None else am_h[s0:s1], outs, s0, False)
-                    done = torch.cuda.Event()
-                    done.record(st)
-                main.wait_event(done)

@@ -429,9 +429,9 @@ def _rank_case(cuda, name, pairs_per_forward):
     assert sep >= 0.999
 
 
-def test_streams_and_last_layer_trimming_are_invisible(cuda):
-    """production path (2 HIP streams, last decoder layer evaluated only on the rows the heads read) vs the plain
-    single-stream full evaluation: every output field bit-identical (per-sample math is unchanged)"""
+def test_last_layer_trimming_is_invisible(cuda):
+    """production path (last decoder layer evaluated only on the 2 rows per sample the heads read) vs the full evaluation
+    of every row (the debug-probe mode): every output field bit-identical at these shapes"""
     from mj_video_amd import synth
     cfg = make_cfg("2b", 224)
     sd = synth.synth_state_dict(cfg, seed=0, lm_head=False)
@@ -441,15 +441,11 @@ def test_streams_and_last_layer_trimming_are_invisible(cuda):
     vids = [dict(video_idx=i, n_tiles=t, caption_seed=i) for i, t in enumerate([8, 6, 8, 3, 5])]
     px, ids, mask, _ = case_inputs(cfg, vids, 77, 224)
     px, ids, mask = px.to(cuda), ids.to(cuda), mask.to(cuda)
-    model.n_streams = 2
-    fast = model.forward(px, ids, mask)
-    model.n_streams = 1
     one = model.forward(px, ids, mask)
     model.debug_probes = {}
     full = model.forward(px, ids, mask)
     model.debug_probes = None
     for f in FIELDS:
-        assert torch.equal(getattr(fast, f), getattr(full, f)), f
         assert torch.equal(getattr(one, f), getattr(full, f)), f
 
 
