@@ -23,8 +23,13 @@ MJV_DEV u16 f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(u16, b);
 }
-// round an fp32 value through bf16 (a torch op boundary in the reference's bf16 path)
-MJV_DEV float rbf(float f) { return bf2f(f2bf(f)); }
+// round an fp32 value through bf16 (a torch op boundary in the reference's bf16 path): ONE v_cvt_pk_bf16_f32 with the value
+// in the HIGH half and zero in the low half - the packed word is the rounded value's fp32 bit pattern, no shift / mask
+typedef __attribute__((ext_vector_type(2))) float mjv_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 mjv_bf16x2;
+MJV_DEV float rbf(float f) {
+  return __builtin_bit_cast(float, __builtin_convertvector(mjv_f32x2{0.f, f}, mjv_bf16x2));
+}
 MJV_DEV unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
 MJV_DEV void unpack8(const u32x4& v, float* f) {
