@@ -103,6 +103,9 @@ int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);
  * the tile order (default 8), 1000 / 1003 / 1004 select the 256-tile kernel's timing variants (1003: no epilogue, 1004: no
  * global stores - wrong results by construction, tools/gemm_bench.py only). */
 int mjv_gemm_set_tile(int32_t tile);
+/* diagnostic build of the 256-tile kernel (tile code 1006): wave 0 of every workgroup writes 8 x uint64 s_memtime values
+ * {start stamp, prologue, main loop, epilogue pass A, epilogue pass B, total cycles} to this device buffer; NULL = off */
+int mjv_gemm_stamp_buffer(void* device_buffer);
 
 /* ---------------------------------------------------------------------------------------------
  * Flash-style attention over packed variable-length sequences (no N x N scores in HBM).

@@ -67,6 +67,7 @@ SYMBOLS = {
     "mjv_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _VP]),
     "mjv_gemm_workspace_bytes": (C.c_int64, []),
     "mjv_gemm_set_tile": (C.c_int, [_I32]),
+    "mjv_gemm_stamp_buffer": (C.c_int, [_VP]),
     "mjv_attention_bf16": (C.c_int, [C.POINTER(AttnDesc), _VP]),
     "mjv_attention_set_variant": (C.c_int, [_I32]),
     "mjv_layernorm_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, _F, _I32, _VP]),

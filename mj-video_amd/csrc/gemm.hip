@@ -530,6 +530,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const int a_half = 2 + wr;   // this wave's activation half-tile index within a K-tile
   const int w_half = wc >> 1;  // this wave's weight half-tile index
 
+  // VAR 6 (diagnostic build, tools/gemm_bench.py): s_memtime stamps of wave 0 -> p.ws as 8 x uint64 per workgroup
+  // {start, prologue done, main loop done, pass A done, end}: the shares of a tile's life, never its length
+  auto stamp = [&]() -> unsigned long long {
+    if constexpr (VAR == 6) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      return t;
+    } else {
+      return 0ull;
+    }
+  };
+  const unsigned long long t_start = stamp();
   StagePtrs sp;
   init_stage_ptrs(sp, p, m0, n0, wave, lane);
   // ---- prologue: K-tile 0 completely, W halves of K-tile 1
@@ -543,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   MJV_BARRIER();
   if (wr == 1) MJV_BARRIER();  // stagger the second M-group by one barrier
+  const unsigned long long t_pro = stamp();
 
   bf16x8 af[4][2], wf[2][2][2];  // af[i][kk]; wf[ns][j][kk]
 
@@ -596,6 +611,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     MJV_BARRIER();
   }
   if (wr == 0) MJV_BARRIER();  // matches the stagger barrier of the second M-group
+  const unsigned long long t_main = stamp();
 #undef MJV_LOAD_A
 #undef MJV_LOAD_W
 #undef MJV_MFMA
@@ -648,8 +664,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + b4[r];
         if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+          // fast path when every element of every lane of the wave lies inside the table (|x| in [2^-23, 5.56): all but
+          // one activation in ~10^7 for unit-scale inputs): magnitude - LO + sign * R indexes the table directly, 8 vector
+          // instructions per element instead of 16; otherwise the general form (x/2 below, x or -0 above the table)
+          unsigned ub[4], rel[4];
+          bool all_in = true;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_lut(rbf(v[r]), gtab);
+          for (int r = 0; r < 4; ++r) {
+            ub[r] = __float_as_uint(rbf(v[r]));
+            rel[r] = ((ub[r] >> 16) & 0x7fffu) - MJV_GELU_LO;
+            all_in = all_in && (rel[r] < (unsigned)MJV_GELU_R);
+          }
+          if (__all(all_in)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const unsigned idx = rel[r] + (ub[r] >> 31) * (unsigned)MJV_GELU_R;
+              v[r] = __uint_as_float((unsigned)gtab[idx] << 16);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_lut(__uint_as_float(ub[r]), gtab);
+          }
         } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -660,6 +695,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       *(u32x2*)(etile + ml * EPI_PITCH + col * 2) = o;
     }
   }
+  const unsigned long long t_passA = stamp();
   {
     constexpr int LANES_PER_ROW = OUT_COLS / 8;          // 16-B chunks per output row
     constexpr int ROWS_PER_PASS = 512 / LANES_PER_ROW;
@@ -780,6 +816,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       }
     }
   }
+  if constexpr (VAR == 6) {
+    const unsigned long long t_end = stamp();
+    if (p.ws && tid == 0) {
+      unsigned long long* d = (unsigned long long*)p.ws + (long)blockIdx.x * 8;
+      d[0] = t_start; d[1] = t_pro - t_start; d[2] = t_main - t_pro; d[3] = t_passA - t_main; d[4] = t_end - t_passA;
+      d[5] = t_end - t_start;
+    }
+  }
 }
 
 }  // namespace t256
@@ -790,7 +834,8 @@ int g_gm = 8;
 int g_skinny_max_m = 128;   // problems with at most this many rows run on the 64 x 32 kernel (tile codes 6000 + m; 6000 = off)
 int g_split_max = 8;  // cap on the slices per tile (tile codes 4100 + cap, experiments)
 int g_split_k = 1;  // 1 = split-K for under-filled 128-tile launches when the caller gives a workspace (tile codes 4001 / 4000)
-int g_variant = 0;  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
+int g_variant = 0;
+void* g_stamp_buffer = nullptr;  // variant 6: device buffer for the s_memtime stamps (mjv_gemm_stamp_buffer)  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
 
 template <int EPI>
 int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
@@ -813,12 +858,16 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     attr_done.fetch_or(bit, std::memory_order_release);   // racing first calls both set the attributes: idempotent
   }
   if (big) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
-    if (g_variant == 4)
+    if (g_variant == 6) {
+      a.ws = (float*)g_stamp_buffer;
+      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 6>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+    } else if (g_variant == 4)
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
     else if (g_variant == 3)
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
@@ -870,6 +919,12 @@ extern "C" int mjv_gemm_set_tile(int32_t tile) {
   }
   g_force_tile = tile;
   if (tile == 0) g_variant = 0;   // "automatic" also leaves the experimental kernel variants
+  return MJV_OK;
+}
+
+// diagnostic (variant 1006): 8 x uint64 per workgroup of the following 256-tile launches go to this device buffer
+extern "C" int mjv_gemm_stamp_buffer(void* p) {
+  g_stamp_buffer = p;
   return MJV_OK;
 }
 
