@@ -639,6 +639,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     __syncthreads();
   }
   constexpr int OUT_COLS = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
+  // pass B geometry: 32 (16 for SiLU) lanes x 16 B = one output row per pass
+  constexpr int LANES_PER_ROW = OUT_COLS / 8;          // 16-B chunks per output row
+  constexpr int ROWS_PER_PASS = 512 / LANES_PER_ROW;
+  constexpr int PASSES = 256 / ROWS_PER_PASS;
+  const int c8 = (tid % LANES_PER_ROW) * 8;
+  const int nout0 = (EPI == MJV_EPI_SILU_MUL) ? n0 / 2 : n0;
+  const int nlim = (EPI == MJV_EPI_SILU_MUL) ? p.N / 2 : p.N;
+  const int n = nout0 + c8;
+  const int ml0 = tid / LANES_PER_ROW;
+  // residual rows of this thread's 16 output chunks: issued BEFORE pass A - the operand fragment registers of the main
+  // loop (64 per lane) are dead, and s_memtime stamps put 13-19 k of a SCALE_RES tile's 15-22 k pass-B cycles on this
+  // 128 KB-per-CU read arriving at the per-CU share of HBM bandwidth; pass A (2.7 k cycles) and the barrier now run under it
+  u32x4 rsv[(EPI == MJV_EPI_SCALE_RES) ? PASSES : 1];
+  float sc[8];
+  if constexpr (EPI == MJV_EPI_SCALE_RES) {
+    if (p.scale && n < nlim) unpack8(*(const u32x4*)(p.scale + n), sc);
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+      const int ml = it * ROWS_PER_PASS + ml0;
+      rsv[it] = u32x4{0u, 0u, 0u, 0u};
+      if (m0 + ml < p.M && n < nlim) {
+        const int m = p.m_base + m0 + ml;
+        const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;   // uniform branch
+        rsv[it] = *(const u32x4*)(p.res + rrow * p.ldr + n);
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int nl = wc * 64 + j * 16 + l4 * 4;   // column inside the 256-wide weight tile
@@ -697,31 +724,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   }
   const unsigned long long t_passA = stamp();
   {
-    constexpr int LANES_PER_ROW = OUT_COLS / 8;          // 16-B chunks per output row
-    constexpr int ROWS_PER_PASS = 512 / LANES_PER_ROW;
-    constexpr int PASSES = 256 / ROWS_PER_PASS;
-    const int c8 = (tid % LANES_PER_ROW) * 8;
-    const int nout0 = (EPI == MJV_EPI_SILU_MUL) ? n0 / 2 : n0;
-    const int nlim = (EPI == MJV_EPI_SILU_MUL) ? p.N / 2 : p.N;
-    const int n = nout0 + c8;
-    const int ml0 = tid / LANES_PER_ROW;
-    // residual rows of this thread's 16 output chunks: issued BEFORE the barrier (the accumulators are dead once
-    // pass A has written them, so their registers hold the loads in flight while the workgroup synchronises)
-    u32x4 rsv[(EPI == MJV_EPI_SCALE_RES) ? PASSES : 1];
-    float sc[8];
-    if constexpr (EPI == MJV_EPI_SCALE_RES) {
-      if (p.scale && n < nlim) unpack8(*(const u32x4*)(p.scale + n), sc);
-#pragma unroll
-      for (int it = 0; it < PASSES; ++it) {
-        const int ml = it * ROWS_PER_PASS + ml0;
-        rsv[it] = u32x4{0u, 0u, 0u, 0u};
-        if (m0 + ml < p.M && n < nlim) {
-          const int m = p.m_base + m0 + ml;
-          const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;   // uniform branch
-          rsv[it] = *(const u32x4*)(p.res + rrow * p.ldr + n);
-        }
-      }
-    }
     if constexpr (EPI == MJV_EPI_ROPE_QKV) {
       // wqkv: the 256-column tile holds two whole 128-wide heads, so a row's rotate_half partner (column d +- 64 of the
       // same head) is in the staged tile.  q / k heads: out = bf16(bf16(x cos) + bf16(rot sin)) to the de-interleaved q / k
