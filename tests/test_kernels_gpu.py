@@ -418,6 +418,31 @@ def test_gemm_pipeline_race_screen(cuda):
         ops.gemm_set_tile(0)
 
 
+def test_gemm_skinny_pipeline_race_screen(cuda):
+    """the 64 x 32 kernel keeps two K-tiles of LDS-DMA in flight across its one barrier per K-tile (counted vmcnt, three
+    buffers): repeat exact-integer problems of the shapes it serves (tails of 64 / 80 rows, deep and shallow K, the gating
+    layers' handful of rows) on a chip kept busy by a large GEMM on another stream; every run bit-identical to the exact result"""
+    from mj_video_amd import ops
+    g = torch.Generator().manual_seed(17)
+    side = torch.cuda.Stream()
+    big_a = torch.randn(8192, 2048, device=cuda).to(BF)
+    big_w = torch.randn(4096, 2048, device=cuda).to(BF)
+    big_o = torch.empty(8192, 4096, dtype=BF, device=cuda)
+    for (M, N, K) in [(64, 3072, 1024), (64, 1024, 4096), (80, 2048, 2048), (7, 1024, 2048), (128, 256, 8192)]:
+        a = torch.randint(-2, 3, (M, K), generator=g).float().to(BF).to(cuda)
+        w = torch.randint(-2, 3, (N, K), generator=g).float().to(BF).to(cuda)
+        a = a * (torch.rand(M, K, generator=g) < 0.2).to(BF).to(cuda)    # keep |sum| < 256: exact in bf16
+        ref = (a.float() @ w.float().t()).to(BF)
+        out = torch.empty(M, N, dtype=BF, device=cuda)
+        for it in range(12):
+            with torch.cuda.stream(side):
+                ops.gemm(big_a, big_w, big_o, ops.EPI_BIAS)
+            out.zero_()
+            ops.gemm(a, w, out, ops.EPI_BIAS)
+            assert torch.equal(out, ref), f"M={M} N={N} K={K} iteration {it}: {(out != ref).sum().item()} wrong elements"
+    torch.cuda.synchronize()
+
+
 def test_gemm_tail_peeling_is_invisible(cuda):
     """(operands in {-1,0,1}, K=256: every intermediate is an integer below 256, exact in bf16 at both rounding points)
     automatic tile choice peels the under-filled last round into a second (128x128-tile) launch: results must not
