@@ -92,7 +92,7 @@ typedef struct mjv_gemm_desc {
   int32_t rope_group;                    /* q heads per kv head */
 } mjv_gemm_desc;
 
-/* a workspace of this size is enough for every problem shape (512 partial 128x128 fp32 tiles) */
+/* a workspace of this size is enough for every problem shape (256 partial 256x256 fp32 tiles = 64 MiB) */
 int64_t mjv_gemm_workspace_bytes(void);
 
 int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);

@@ -508,9 +508,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const int wr = wave >> 2, wc = wave & 3;   // wave owns output rows m: wr*128.., columns n: wc*64..
   const int l15 = lane & 15, l4 = lane >> 4;
   int tm, tn;
-  tile_of_block(p, tm, tn);
+  // VAR 7: split-K slice of a tile (workgroup b = tile b / split, slice b % split), as in the 128-tile kernel: the
+  // accumulators go to the fp32 workspace as they sit in registers, splitk_finish256_kernel sums them in slice order
+  constexpr bool SPLIT = VAR == 7;
+  const int tile_id = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x;
+  const int slice = SPLIT ? (int)blockIdx.x % p.split : 0;
+  tile_of_vblock(p, SPLIT ? (int)gridDim.x / p.split : (int)gridDim.x, tile_id, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = p.K / BK;
+  const int nk_all = p.K / BK;
+  const int kt0 = SPLIT ? (int)((long)nk_all * slice / p.split) : 0;          // this slice's K-tiles [kt0, kt0 + nk)
+  const int nk = (SPLIT ? (int)((long)nk_all * (slice + 1) / p.split) : nk_all) - kt0;
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -546,6 +553,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const unsigned long long t_start = stamp();
   StagePtrs sp;
   init_stage_ptrs(sp, p, m0, n0, wave, lane);
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int which = 0; which < 4; ++which)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sp.src[which][i] += kt0 * BK;
+  }
   // ---- prologue: K-tile 0 completely, W halves of K-tile 1
   stage_half<0>(sp, 0, nk, smem, wave);
   stage_half<1>(sp, 0, nk, smem, wave);
@@ -617,6 +630,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef MJV_MFMA
 #undef MJV_MFMA_K
 
+  if constexpr (SPLIT) {
+    f32x4* img = (f32x4*)p.ws + ((long)tile_id * p.split + slice) * (32 * 512) + tid;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) img[(i * 4 + j) * 512] = acc[i][j];
+    return;
+  }
   if constexpr (VAR == 3) {  // timing experiment: main loop only (accumulators kept alive, nothing stored)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -828,6 +849,48 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   }
 }
 
+// Second half of a 256-tile split-K launch: 8 workgroups per tile (workgroup = 32 output rows of each of the tile's 8
+// waves' row blocks, i.e. fragment row i of every thread of the GEMM workgroup) so that the fp32 slices - a few tens of MB -
+// are read by a few hundred workgroups, not by one per tile; per fragment, sums the slices' register images in slice order
+// (deterministic) and runs the per-fragment epilogue of the small kernels.
+template <int EPI>
+__global__ __launch_bounds__(512) void splitk_finish256_kernel(GemmArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int tile_id = (int)blockIdx.x >> 3, i = (int)blockIdx.x & 7;
+  int tm, tn;
+  tile_of_vblock(p, (int)gridDim.x >> 3, tile_id, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const f32x4* img = (const f32x4*)p.ws + (long)tile_id * p.split * (32 * 512) + tid;
+  f32x4 fr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fr[j] = img[(i * 4 + j) * 512];
+  for (int sl = 1; sl < p.split; ++sl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fr[j] += img[(long)sl * (32 * 512) + (i * 4 + j) * 512];
+  }
+  const int mrel = m0 + wr * 128 + i * 16 + l15;
+  if (mrel >= p.M) return;
+  const int m = p.m_base + mrel;
+  const long orow = out_row_of(p, m);
+  if constexpr (EPI == MJV_EPI_SILU_MUL) {
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      const int n = n0 + wc * 64 + j * 16 + l4 * 4;
+      if (n >= p.N) continue;
+      store_silu(p, fr[j], fr[j + 1], orow, n0 / 2 + wc * 32 + (j / 2) * 16 + l4 * 4);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + l4 * 4;
+      if (n >= p.N) continue;
+      store_frag<EPI>(p, fr[j], m, orow, n);
+    }
+  }
+}
+
 }  // namespace t256
 
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
@@ -838,6 +901,9 @@ int g_split_max = 8;  // cap on the slices per tile (tile codes 4100 + cap, expe
 int g_split_k = 1;  // 1 = split-K for under-filled 128-tile launches when the caller gives a workspace (tile codes 4001 / 4000)
 int g_variant = 0;
 void* g_stamp_buffer = nullptr;  // variant 6: device buffer for the s_memtime stamps (mjv_gemm_stamp_buffer)  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
+
+int g_split256_min_kt = 8;   // fewest K-tiles per slice (tile codes 4300 + n, experiments)
+int g_split256 = 1;   // 1 = under-filled problems with deep K run as split-K slices of 256 x 256 tiles (tile codes 4201 / 4200)
 
 template <int EPI>
 int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
@@ -861,12 +927,17 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<MJV_EPI_BIAS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     attr_done.fetch_or(bit, std::memory_order_release);   // racing first calls both set the attributes: idempotent
   }
   if (big) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
-    if (g_variant == 6) {
+    if (a.split > 1) {
+      const int tiles = a.tiles_m * a.tiles_n;
+      hipLaunchKernelGGL((t256::gemm256_kernel<MJV_EPI_BIAS, 7>), dim3(tiles * a.split), dim3(512), t256::LDS_BYTES, s, a);
+      hipLaunchKernelGGL(t256::splitk_finish256_kernel<EPI>, dim3(tiles * 8), dim3(512), 0, s, a);
+    } else if (g_variant == 6) {
       a.ws = (float*)g_stamp_buffer;
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 6>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
     } else if (g_variant == 4)
@@ -891,7 +962,7 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
 
 }  // namespace
 
-extern "C" int64_t mjv_gemm_workspace_bytes(void) { return 512L * 65536L; }
+extern "C" int64_t mjv_gemm_workspace_bytes(void) { return 256L * 262144L; }
 
 extern "C" int mjv_gemm_set_tile(int32_t tile) {
   if (tile > 4100 && tile <= 4108) {
@@ -900,6 +971,14 @@ extern "C" int mjv_gemm_set_tile(int32_t tile) {
   }
   if (tile >= 6000 && tile <= 6512) {  // 6000 + m: largest M of the skinny kernel (6000 switches it off; A/B measurements)
     g_skinny_max_m = tile - 6000;
+    return MJV_OK;
+  }
+  if (tile > 4300 && tile <= 4364) {
+    g_split256_min_kt = tile - 4300;
+    return MJV_OK;
+  }
+  if (tile == 4200 || tile == 4201) {  // split-K on 256 x 256 tiles off / on (A/B measurements)
+    g_split256 = tile - 4200;
     return MJV_OK;
   }
   if (tile == 4000 || tile == 4001) {  // split-K of under-filled 128-tile launches off / on (A/B measurements)
@@ -988,6 +1067,8 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   }
   static const char* const tags256[] = {"gemm256_bias", "gemm256_bias_gelu", "gemm256_bias_relu", "gemm256_scale_res",
                                         "gemm256_silu_mul", "gemm256_rope_qkv"};
+  static const char* const tags256s[] = {"gemm256s_bias", "gemm256s_bias_gelu", "gemm256s_bias_relu", "gemm256s_scale_res",
+                                         "gemm256s_silu_mul"};
   static const char* const tags128[] = {"gemm128_bias", "gemm128_bias_gelu", "gemm128_bias_relu", "gemm128_scale_res",
                                         "gemm128_silu_mul"};
   if (d->epilogue < 0 || d->epilogue > MJV_EPI_ROPE_QKV) {
@@ -1014,23 +1095,43 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   };
   static const char* const tags64[] = {"gemm64_bias", "gemm64_bias_gelu", "gemm64_bias_relu", "gemm64_scale_res",
                                        "gemm64_silu_mul"};
+  // Under-filled problems with deep K (K >= 4096: the ~1100-row tail of the language tower's w2, and the whole w2 of a
+  // single-video forward): K slices of 256 x 256 tiles, one workgroup per CU, at most one round - the 256 kernel's main
+  // loop moves 1.4-1.6x the flops per CU-second of the 128 kernel's, which pays for the fp32 round trip of the slices
+  // (tools/gemm_bench.py, MJV_BENCH_TAILS=1: 1104 x 2048 x 8192 in 56 us against 64 us on sliced 128 tiles and 141 us on
+  // unsliced 256 tiles; 2186 rows: 83 against 145 us).  At K = 2048 it is a wash or a loss (wqkv tail 41 -> 44 us): not used.
+  auto plan_split256 = [&](GemmArgs& g) -> bool {
+    if (!g_split256 || g_force_tile || !d->workspace || d->out_rows) return false;
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), nk = g.K / 64;
+    // (a last m-tile that is mostly empty wastes its share of every slice: 138 rows x 16384 columns ran 10 % slower sliced)
+    const bool filled = (long)g.M * 10 >= (long)((g.M + 255) / 256) * 256 * 7;
+    if (g.M <= g_skinny_max_m || g.N < 256 || nk < 64 || tiles * 2 > g_num_cus || !filled) return false;
+    int sp = g_num_cus / tiles;
+    if (sp > g_split_max) sp = g_split_max;
+    if (sp > nk / g_split256_min_kt) sp = nk / g_split256_min_kt;
+    if (sp < 2 || (long)tiles * sp * 262144L > d->workspace_bytes) return false;
+    g.split = sp;
+    g.ws = (float*)d->workspace;
+    return true;
+  };
   auto run = [&](GemmArgs g, bool use_big) -> int {
+    if (plan_split256(g)) use_big = true;
     // skinny problems (peeled tails of a few dozen rows, batch-sized head layers): the 64 x 32 kernel
     const bool skinny = !use_big && (g_force_tile ? g_force_tile == 64 : g.M <= g_skinny_max_m);
     if (!use_big && !skinny) plan_split(g);
     const double frac = (double)g.M / (double)d->M;
-    // the rotary epilogue needs a whole 256-column tile staged in LDS: only the 256^2 kernel has it.  Rows that run on the
-    // smaller kernels (peeled tails, small problems) get the plain Linear into C and the standalone rope_split kernel.
-    const int epi = (d->epilogue == MJV_EPI_ROPE_QKV && !use_big) ? (int)MJV_EPI_BIAS : d->epilogue;
+    // the rotary epilogue needs a whole 256-column tile staged in LDS: only the unsplit 256^2 kernel has it.  Rows that run
+    // on the other kernels (peeled tails, small problems) get the plain Linear into C and the standalone rope_split kernel.
+    const int epi = (d->epilogue == MJV_EPI_ROPE_QKV && (!use_big || g.split > 1)) ? (int)MJV_EPI_BIAS : d->epilogue;
     int rc;
     {
-      MjvProfScope ps(use_big ? tags256[epi] : skinny ? tags64[epi] : tags128[epi], s, flops * frac, bytes * frac);
+      MjvProfScope ps(use_big ? (g.split > 1 ? tags256s[epi] : tags256[epi]) : skinny ? tags64[epi] : tags128[epi], s, flops * frac, bytes * frac);
       switch (epi) {
         case MJV_EPI_BIAS: rc = launch<MJV_EPI_BIAS>(g, s, use_big, skinny); break;
         case MJV_EPI_BIAS_GELU: rc = launch<MJV_EPI_BIAS_GELU>(g, s, use_big, skinny); break;
         case MJV_EPI_BIAS_RELU: rc = launch<MJV_EPI_BIAS_RELU>(g, s, use_big, skinny); break;
         case MJV_EPI_SCALE_RES: rc = launch<MJV_EPI_SCALE_RES>(g, s, use_big, skinny); break;
-        case MJV_EPI_ROPE_QKV: rc = launch<MJV_EPI_ROPE_QKV>(g, s, true, false); break;
+        case MJV_EPI_ROPE_QKV: rc = launch<MJV_EPI_ROPE_QKV>(g, s, true, false); break;   // unsplit 256 kernel only
         default: rc = launch<MJV_EPI_SILU_MUL>(g, s, use_big, skinny); break;
       }
     }

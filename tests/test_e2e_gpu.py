@@ -163,6 +163,12 @@ def _full_case(cuda, tag, image_size):
     tiles = meta["videos"][0]["n_tiles"]
     cu_rows = np.concatenate([[0], np.cumsum([int(m.sum()) for m in mask])])
     layer_report, dev_by_field = [], {f: [] for f in _PACKED34}
+    # hidden-state rows the heads read: the reference's bf16 run is itself 2.2-2.6 % (relative L2) away from its fp32 run at
+    # these rows; two independent samples of that noise differ by sqrt(2) x as much, so the HIP path is held to 1.5 x the
+    # largest bf16-vs-fp32 distance the fixture recorded for the field (a re-associated fp32 sum - e.g. a K-sliced GEMM -
+    # moves these rows by about 1 % of their norm without moving them away from the fp32 truth)
+    hid_tol = {f: 1.5 * max(rel_l2(npz[f"{q}/{f}"], npz[f"{q}/fp32/{f}"]) for q in with_fp32)
+               for f in ("hidden_state", "prompt_embedding")}
     for i, v in enumerate(meta["videos"]):
         p = f"v{v['video_idx']}"
         if f"{p}/probe/vit_embed_head" in npz.files:
@@ -196,7 +202,8 @@ def _full_case(cuda, tag, image_size):
             got = getattr(out, f)[i].float().cpu().numpy()
             ref = npz[f"{p}/{f}"][0]
             if f in ("hidden_state", "prompt_embedding"):
-                assert rel_l2(got, ref) < 0.03, (tag, p, f, rel_l2(got, ref))
+                print(f"{tag} {p} {f}: rel-L2 {rel_l2(got, ref):.4f} (bound {hid_tol[f]:.4f})")
+                assert rel_l2(got, ref) < hid_tol[f], (tag, p, f, rel_l2(got, ref), hid_tol[f])
                 continue
             tol = TOL_FACTOR * max(noise_floor(npz, with_fp32, f), pooled_noise_floor(f)) + ATOL_FLOOR
             d = float(np.abs(got - ref).max())
@@ -431,8 +438,10 @@ def _rank_case(cuda, name, pairs_per_forward):
 
 def test_last_layer_trimming_is_invisible(cuda):
     """production path (last decoder layer evaluated only on the 2 rows per sample the heads read) vs the full evaluation
-    of every row (the debug-probe mode): every output field bit-identical at these shapes"""
-    from mj_video_amd import synth
+    of every row (the debug-probe mode): every output field bit-identical at these shapes when both runs sum K in one
+    order (K-slicing of under-filled GEMMs off: the 2 700-row full evaluation would otherwise run its K = 8192 GEMM as two
+    slices while the 10 trimmed rows never do); with slicing on, the two differ like any re-associated fp32 sum"""
+    from mj_video_amd import synth, ops
     cfg = make_cfg("2b", 224)
     sd = synth.synth_state_dict(cfg, seed=0, lm_head=False)
     sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
@@ -441,12 +450,26 @@ def test_last_layer_trimming_is_invisible(cuda):
     vids = [dict(video_idx=i, n_tiles=t, caption_seed=i) for i, t in enumerate([8, 6, 8, 3, 5])]
     px, ids, mask, _ = case_inputs(cfg, vids, 77, 224)
     px, ids, mask = px.to(cuda), ids.to(cuda), mask.to(cuda)
-    one = model.forward(px, ids, mask)
-    model.debug_probes = {}
-    full = model.forward(px, ids, mask)
-    model.debug_probes = None
-    for f in FIELDS:
-        assert torch.equal(getattr(one, f), getattr(full, f)), f
+    try:
+        ops.gemm_set_tile(4200)
+        ops.gemm_set_tile(4000)
+        one = model.forward(px, ids, mask)
+        model.debug_probes = {}
+        full = model.forward(px, ids, mask)
+        model.debug_probes = None
+        for f in FIELDS:
+            assert torch.equal(getattr(one, f), getattr(full, f)), f
+    finally:
+        model.debug_probes = None
+        ops.gemm_set_tile(4201)
+        ops.gemm_set_tile(4001)
+    sliced = model.forward(px, ids, mask)
+    for f in ("hidden_state", "prompt_embedding"):
+        e = rel_l2(getattr(sliced, f).float().cpu().numpy(), getattr(one, f).float().cpu().numpy())
+        print(f"K-sliced vs unsliced {f}: relative L2 {e:.4f}")
+        # not small: one re-associated fp32 sum in the last layers' GEMMs moves these rows as far as the reference's own bf16
+        # run is from its fp32 run (2.2-2.6 %); two samples of that noise differ by up to sqrt(2) x as much
+        assert e < 0.045, (f, e)
 
 
 def test_forward_is_deterministic_at_headline_shape(cuda):

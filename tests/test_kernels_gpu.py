@@ -418,6 +418,54 @@ def test_gemm_pipeline_race_screen(cuda):
         ops.gemm_set_tile(0)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1104, 2048, 8192, "scale_res"), (1104, 4096, 4096, "bias"), (2186, 2048, 8192, "scale_res"),
+                                       (600, 1024, 4096, "silu"), (400, 520, 4160, "relu")])
+def test_gemm_split_k_on_256_tiles(cuda, M, N, K, epi):
+    """under-filled problems with deep K (the ~1100-row tails of the language tower, the whole GEMMs of a single-video
+    forward) run as K slices of 256 x 256 tiles when the caller gives a workspace; exact-integer operands: the sliced result
+    equals the unsliced one and the fp32 reference bit for bit, for every epilogue of the finishing kernel"""
+    from mj_video_amd import ops
+    g = torch.Generator().manual_seed(19)
+    a = torch.randint(-1, 2, (M, K), generator=g).float().to(BF).to(cuda)
+    w = torch.randint(-1, 2, (N, K), generator=g).float().to(BF).to(cuda)
+    a = a * (torch.rand(M, K, generator=g) < 0.15).to(BF).to(cuda)
+    bias = torch.randint(-2, 3, (N,), generator=g).float().to(BF).to(cuda)
+    res = torch.randint(-8, 9, (M, N if epi != "silu" else N // 2), generator=g).float().to(BF).to(cuda)
+    kw = {"bias": dict(epilogue=ops.EPI_BIAS, bias=bias), "relu": dict(epilogue=ops.EPI_BIAS_RELU, bias=bias),
+          "scale_res": dict(epilogue=ops.EPI_SCALE_RES, bias=bias, res=res), "silu": dict(epilogue=ops.EPI_SILU_MUL)}[epi]
+    nout = N // 2 if epi == "silu" else N
+    ws = torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=cuda)
+    outs = []
+    try:
+        ops.set_gemm_workspace(ws)
+        for code in (4201, 4200):          # sliced 256 tiles on / off (off: the 128-tile kernels, as before)
+            ops.gemm_set_tile(code)
+            ws.fill_(255)
+            out = torch.full((M, nout), 7.0, dtype=BF, device=cuda)
+            ops.gemm(a, w, out, **kw)
+            outs.append(out.clone())
+            if code == 4201:               # a whole 256 x 256 fp32 slice image is finite only if the sliced path wrote it
+                assert bool(torch.isfinite(ws[:262144].view(torch.float32)).all()), "256-tile split-K path not taken"
+    finally:
+        ops.gemm_set_tile(4201)
+        ops.gemm_set_tile(0)
+        ops.set_gemm_workspace(None)
+    assert torch.equal(outs[0], outs[1])
+    lin = a.float() @ w.float().t()
+    if epi == "bias":
+        ref = (lin + bias.float()).to(BF)
+    elif epi == "relu":
+        ref = F.relu((lin + bias.float()).to(BF))
+    elif epi == "scale_res":
+        ref = (res.float() + (lin + bias.float()).to(BF).float()).to(BF)
+    else:
+        lin16 = lin.to(BF).view(M, N // 32, 2, 16)
+        ref = (F.silu(lin16[:, :, 0]) * lin16[:, :, 1]).reshape(M, N // 2)
+        assert_close_bf16(outs[0], ref, 3, frac_exact=0.95, atol=2e-3, what="split_k256_silu")
+        return
+    assert torch.equal(outs[0], ref)
+
+
 def test_gemm_skinny_pipeline_race_screen(cuda):
     """the 64 x 32 kernel keeps two K-tiles of LDS-DMA in flight across its one barrier per K-tile (counted vmcnt, three
     buffers): repeat exact-integer problems of the shapes it serves (tails of 64 / 80 rows, deep and shallow K, the gating

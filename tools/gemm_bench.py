@@ -20,8 +20,18 @@ def bench(M, N, K, epi, tile, iters=20):
     bias = torch.randn(N, device=dev).to(BF) if epi not in (ops.EPI_SILU_MUL,) else None
     res = torch.randn(M, nout, device=dev).to(BF) if epi == ops.EPI_SCALE_RES else None
     scale = torch.randn(N, device=dev).to(BF) if epi == ops.EPI_SCALE_RES else None
-    if tile >= 5000:      # 5000 + tile: same tile choice with a split-K workspace
+    if tile == 9000:      # automatic tile choice with a workspace, 256-tile split-K switched off (A/B against 5000)
         global WS
+        WS = WS if WS is not None else torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ops.set_gemm_workspace(WS)
+        ops.gemm_set_tile(4200)
+        ops.gemm_set_tile(0)
+    elif 9000 < tile <= 9064:      # as 5000 with at least tile - 9000 K-tiles per slice of the 256-tile split-K
+        WS = WS if WS is not None else torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ops.set_gemm_workspace(WS)
+        ops.gemm_set_tile(4300 + tile - 9000)
+        ops.gemm_set_tile(0)
+    elif tile >= 5000:      # 5000 + tile: same tile choice with a split-K workspace
         WS = WS if WS is not None else torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
         ops.set_gemm_workspace(WS)
         ops.gemm_set_tile(tile - 5000)
@@ -39,7 +49,7 @@ def bench(M, N, K, epi, tile, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    ops.gemm_set_tile(2008); ops.gemm_set_tile(0); ops.set_gemm_workspace(None)
+    ops.gemm_set_tile(2008); ops.gemm_set_tile(4201); ops.gemm_set_tile(4308); ops.gemm_set_tile(0); ops.set_gemm_workspace(None)
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
@@ -55,7 +65,11 @@ if os.environ.get("MJV_BENCH_TAILS"):   # the peeled tail problems of the model'
               ("tail_vit_fc1", 64, 4096, 1024, ops.EPI_BIAS_GELU), ("tail_vit_fc2", 64, 1024, 4096, ops.EPI_SCALE_RES),
               ("tail_llm_wqkv", 1104, 4096, 2048, ops.EPI_BIAS), ("tail_llm_wo", 1104, 2048, 2048, ops.EPI_SCALE_RES),
               ("tail_llm_w13", 80, 16384, 2048, ops.EPI_SILU_MUL), ("tail_llm_w2", 1104, 2048, 8192, ops.EPI_SCALE_RES),
-              ("main_llm_w2", 16384, 2048, 8192, ops.EPI_SCALE_RES), ("main_vit_fc2", 65536, 1024, 4096, ops.EPI_SCALE_RES)]
+              ("main_llm_w2", 16384, 2048, 8192, ops.EPI_SCALE_RES), ("main_vit_fc2", 65536, 1024, 4096, ops.EPI_SCALE_RES),
+              # whole GEMMs of a single-video forward (the reference's own call pattern)
+              ("b1_llm_wqkv", 2186, 4096, 2048, ops.EPI_BIAS), ("b1_llm_wo", 2186, 2048, 2048, ops.EPI_SCALE_RES),
+              ("b1_llm_w13", 2186, 16384, 2048, ops.EPI_SILU_MUL), ("b1_llm_w2", 2186, 2048, 8192, ops.EPI_SCALE_RES),
+              ("b1_vit_proj", 8200, 1024, 1024, ops.EPI_SCALE_RES), ("b1_vit_fc2", 8200, 1024, 4096, ops.EPI_SCALE_RES)]
 tiles = [int(t) for t in sys.argv[1:]] or [256]
 ROUNDS = 3
 for name, M, N, K, epi in shapes:
