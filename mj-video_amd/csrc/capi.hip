@@ -33,7 +33,7 @@ hipEvent_t get_event() {
     return e;
   }
   hipEvent_t e;
-  hipEventCreate(&e);
+  (void)hipEventCreate(&e);
   return e;
 }
 }  // namespace
@@ -86,7 +86,7 @@ MjvProfScope::MjvProfScope(const char* tag, hipStream_t s, double flops, double 
   r.tag = t;
   r.start = get_event();
   r.stop = get_event();
-  hipEventRecord(r.start, s);
+  (void)hipEventRecord(r.start, s);
   g_recs.push_back(r);
   slot = (int)g_recs.size() - 1;
 }
@@ -94,7 +94,7 @@ MjvProfScope::MjvProfScope(const char* tag, hipStream_t s, double flops, double 
 MjvProfScope::~MjvProfScope() {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  hipEventRecord(g_recs[slot].stop, stream);
+  (void)hipEventRecord(g_recs[slot].stop, stream);
 }
 
 extern "C" {
@@ -118,7 +118,7 @@ int mjv_prof_filter(const char* tag) {
 int mjv_prof_collect(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& r : g_recs) {
-    hipEventSynchronize(r.stop);
+    (void)hipEventSynchronize(r.stop);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) g_tags[r.tag].ms += ms;
     g_pool.push_back(r.start);

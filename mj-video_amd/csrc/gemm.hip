@@ -895,7 +895,7 @@ __global__ __launch_bounds__(512) void splitk_finish256_kernel(GemmArgs p) {
 
 int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
 thread_local int g_num_cus = 256;   // CUs of the device of the call in flight (mjv_device_cus), set in mjv_gemm_bf16
-int g_gm = 8;
+int g_gm = 0;   // group-M of the 256-tile order: 0 = by shape (pick_gm), tile codes 2000 + gm force one value (tuning)
 int g_skinny_max_m = 128;   // problems with at most this many rows run on the 64 x 32 kernel (tile codes 6000 + m; 6000 = off)
 int g_split_max = 8;  // cap on the slices per tile (tile codes 4100 + cap, experiments)
 int g_split_k = 1;  // 1 = split-K for under-filled 128-tile launches when the caller gives a workspace (tile codes 4001 / 4000)
@@ -962,6 +962,12 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
 
 }  // namespace
 
+// Group-M per shape class, from sweeps on the model's shapes (tools/gemm_bench.py 2003 ... 2016, best of 6 rounds, two
+// boxes): the short-K vision GEMMs prefer 5-7 (qkv +2.8 %, proj +6 %, fc1 +2.5 % over 8 - with N = 1024 and GM = 8 a group
+// is exactly the 32 tiles one XCD runs at a time, and all eight XCDs then walk the same four weight panels in step), the
+// K = 8192 GEMM prefers 4 (+1.6 ... +3.8 %), everything between is flat within 1 % and keeps 8.
+static int pick_gm(int K) { return K <= 1024 ? 5 : K >= 8192 ? 4 : 8; }
+
 extern "C" int64_t mjv_gemm_workspace_bytes(void) { return 256L * 262144L; }
 
 extern "C" int mjv_gemm_set_tile(int32_t tile) {
@@ -986,7 +992,7 @@ extern "C" int mjv_gemm_set_tile(int32_t tile) {
     return MJV_OK;
   }
   if (tile >= 2000 && tile < 2100) {  // 2000 + gm: group-M of the tile order (tuning experiments)
-    g_gm = tile - 2000 > 0 ? tile - 2000 : 1;
+    g_gm = tile - 2000;   // 2000: back to the per-shape choice
     return MJV_OK;
   }
   if (tile >= 1000 && tile < 1010) {  // 1000 + v: keep the automatic tile choice, switch the 256-kernel variant
@@ -1041,7 +1047,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.m_base = 0;
   a.ws = nullptr;
   a.split = 1;
-  a.gm = g_gm;
+  a.gm = g_gm > 0 ? g_gm : pick_gm(d->K);
   a.rope_cos = d->rope_cos; a.rope_sin = d->rope_sin; a.rope_pos = d->rope_pos; a.rope_q = d->rope_q; a.rope_k = d->rope_k;
   a.rope_ldq = d->rope_ldq; a.rope_ldk = d->rope_ldk; a.rope_group = d->rope_group;
   a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;

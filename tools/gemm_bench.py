@@ -49,7 +49,7 @@ def bench(M, N, K, epi, tile, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    ops.gemm_set_tile(2008); ops.gemm_set_tile(4201); ops.gemm_set_tile(4308); ops.gemm_set_tile(0); ops.set_gemm_workspace(None)
+    ops.gemm_set_tile(2000); ops.gemm_set_tile(4201); ops.gemm_set_tile(4308); ops.gemm_set_tile(0); ops.set_gemm_workspace(None)
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
@@ -71,7 +71,7 @@ if os.environ.get("MJV_BENCH_TAILS"):   # the peeled tail problems of the model'
               ("b1_llm_w13", 2186, 16384, 2048, ops.EPI_SILU_MUL), ("b1_llm_w2", 2186, 2048, 8192, ops.EPI_SCALE_RES),
               ("b1_vit_proj", 8200, 1024, 1024, ops.EPI_SCALE_RES), ("b1_vit_fc2", 8200, 1024, 4096, ops.EPI_SCALE_RES)]
 tiles = [int(t) for t in sys.argv[1:]] or [256]
-ROUNDS = 3
+ROUNDS = int(os.environ.get("MJV_BENCH_ROUNDS", 3))
 for name, M, N, K, epi in shapes:
     line = f"{name:16s} M={M:6d} N={N:6d} K={K:5d}"
     best = {t: (1e9, 0) for t in tiles}
