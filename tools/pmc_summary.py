@@ -21,6 +21,11 @@ def tag_of(k):
     m = re.match(r"t256::gemm256_kernel<(\d), 0>", k)
     if m:
         return "gemm256_" + EPI[int(m.group(1))]
+    if re.match(r"t256::gemm256_kernel<0, 7>", k):
+        return "gemm256s_slices"        # K-sliced 256-tile launch: fp32 slice images to the workspace
+    m = re.match(r"t256::splitk_finish256_kernel<(\d)>", k)
+    if m:
+        return "gemm256s_finish_" + EPI[int(m.group(1))]
     m = re.match(r"t128::gemm128_kernel<(\d), (true|false)>", k)
     if m:
         return "gemm128_" + EPI[int(m.group(1))] + ("_splitk" if m.group(2) == "true" else "")
