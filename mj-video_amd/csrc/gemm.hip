@@ -4,8 +4,8 @@
 //
 //  * gemm256_kernel - the production shape.  256x256x64 tile, 512 threads (8 waves as 2(M) x 4(N), 128x64 per
 //    wave, 128 accumulator VGPRs), 128 KiB LDS = 2 K-tiles x 4 half-tiles (128 rows x 64 k) of 16 KiB.  Each
-//    K-tile runs as 4 phases {ds_read a register sub-tile | issue ONE half-tile of LDS-DMA two K-tiles ahead |
-//    barrier | 16 MFMA | barrier}; DMA stays in flight across barriers behind a COUNTED s_waitcnt vmcnt(4) once per
+//    K-tile runs as 2 phases {ds_read the register sub-tiles | issue TWO half-tiles of LDS-DMA one / two K-tiles ahead |
+//    barrier | 32 MFMA | barrier}; DMA stays in flight across barriers behind a COUNTED s_waitcnt vmcnt(4) once per
 //    K-tile (never 0 in the steady state), raw s_barrier only.  The two M-groups of waves run one barrier apart,
 //    so on every SIMD one wave is in its MFMA segment while its partner reads LDS / issues DMA
 //    (cdna_hip_programming.md §5 "8-phase template", MI355X_MICROARCH.md "Two waves per SIMD").
@@ -590,36 +590,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   MJV_MFMA_K(MS, NS, 1)                                \
   __builtin_amdgcn_s_setprio(0);
 
+  // Two phases per K-tile, four barriers (round 1 ran four phases of one 64 x 32 quadrant each, eight barriers: the same
+  // reads, DMA and MFMAs cut into segments twice as long run +2 ... +7 % on every model shape - fewer barrier round trips,
+  // and a 16-read segment has a 32-MFMA segment of the partner wave to hide under instead of 8 under 16).
+  //   phase I : read A rows 0-63 and all 64 W columns of K-tile t | DMA the A halves of K-tile t+1 | barrier | 32 MFMA | barrier
+  //   phase II: read A rows 64-127 | DMA the W halves of K-tile t+2 | retire K-tile t+1 (vmcnt) | barrier | 32 MFMA | barrier
+  // Barrier intervals: M-group 0 reads in I_4t (phase I) and I_4t+2 (phase II); group 1 runs one barrier later.  The W halves
+  // of K-tile t are dead after group 1's phase-I reads (I_4t+1), their buffer is refilled from I_4t+2 on; the A halves are
+  // dead after group 1's phase-II reads (I_4t+3), refilled from I_4t+4 on.  K-tile t+1 is retired by every wave before the
+  // barrier that ends its phase-II read segment (group 1: end of I_4t+3), one barrier before group 0 first reads it (I_4t+4).
+  // (One phase per K-tile - all reads, 64 MFMAs, two barriers - fits in 250 VGPRs but needs the DMA issue and its retiring
+  // wait placed per M-group to stay race-free, and then runs 10-20 % slower than this.)
   for (int t = 0; t < nk; ++t) {
     const char* abase = smem + ((t & 1) * 4 + a_half) * HALF_BYTES;
     const char* wbase = smem + ((t & 1) * 4 + w_half) * HALF_BYTES;
-    // phase 1: quadrant (0,0)
     MJV_LOAD_W(0)
+    MJV_LOAD_W(1)
     MJV_LOAD_A(0)
     stage_half<2>(sp, t + 1, nk, smem, wave);   // A rows 0-127 of K-tile t+1
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    MJV_BARRIER();
-    MJV_MFMA(0, 0)
-    MJV_BARRIER();
-    // phase 2: quadrant (0,1)
-    MJV_LOAD_W(1)
     stage_half<3>(sp, t + 1, nk, smem, wave);   // A rows 128-255 of K-tile t+1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
+    MJV_MFMA(0, 0)
     MJV_MFMA(0, 1)
     MJV_BARRIER();
-    // phase 3: quadrant (1,1)
     MJV_LOAD_A(1)
     stage_half<0>(sp, t + 2, nk, smem, wave);   // W rows 0-127 of K-tile t+2
+    stage_half<1>(sp, t + 2, nk, smem, wave);   // W rows 128-255 of K-tile t+2
+    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but the 2 half-tiles of t+2 issued last
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
     MJV_MFMA(1, 1)
-    MJV_BARRIER();
-    // phase 4: quadrant (1,0); retire K-tile t+1 (everything but the 2 half-tiles of t+2 issued last)
-    stage_half<1>(sp, t + 2, nk, smem, wave);                         // W rows 128-255 of K-tile t+2
-    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MJV_BARRIER();
     MJV_MFMA(1, 0)
     MJV_BARRIER();
   }
