@@ -499,7 +499,8 @@ MJV_DEV void stage_half(const StagePtrs& sp, int t, int nk, char* smem, int wave
 // LDS-DMA in the middle of the MFMA segment instead of the load segment (-5 %); a persistent one-workgroup-per-CU form
 // that prefetches the next tile's first K-tile under the epilogue (neutral: s_waitcnt vmcnt is in-order, the first DMA
 // wait also waits for the epilogue's stores); a role-split persistent form where 4 waves issue all DMA and the other 4
-// all global stores (-5...-35 %: spills + half-width pass B).
+// all global stores (-5...-35 %: spills + half-width pass B); touching the residual tile's 1024 cache lines (one dword each)
+// three K-tiles before the end of the main loop so that pass B finds it in L2 (round 2: neutral on proj / fc2 / wo / w2).
 template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
