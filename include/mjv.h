@@ -101,7 +101,7 @@ int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);
  * 6000 + m: largest M the skinny kernel takes (6000 = never; A/B measurements).  Measurement switches, process-wide, never needed
  * for results: 4000 / 4001 split-K of 128-tile launches off / on, 4200 / 4201 K-sliced 256-tile launches (under-filled problems
  * with K >= 4096) off / on, 4100 + s caps the slices per tile at s (1..8), 4300 + n sets the fewest K-tiles per 256-tile slice,
- * 2000 + g forces the group-M of the tile order (2000 = chosen per shape: 5 for K <= 1024, 4 for K >= 8192, else 8),
+ * 2000 + g forces the group-M of the tile order (2000 = chosen per shape: 5 for K <= 1024, 4 for K >= 8192 or N >= 8192, else 8),
  * 1000 / 1003 / 1004 select the 256-tile kernel's timing variants (1003: no epilogue, 1004: no
  * global stores - wrong results by construction, tools/gemm_bench.py only). */
 int mjv_gemm_set_tile(int32_t tile);

@@ -968,8 +968,9 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
 // Group-M per shape class, from sweeps on the model's shapes (tools/gemm_bench.py 2003 ... 2016, best of 6 rounds, two
 // boxes): the short-K vision GEMMs prefer 5-7 (qkv +2.8 %, proj +6 %, fc1 +2.5 % over 8 - with N = 1024 and GM = 8 a group
 // is exactly the 32 tiles one XCD runs at a time, and all eight XCDs then walk the same four weight panels in step), the
-// K = 8192 GEMM prefers 4 (+1.6 ... +3.8 %), everything between is flat within 1 % and keeps 8.
-static int pick_gm(int K) { return K <= 1024 ? 5 : K >= 8192 ? 4 : 8; }
+// K = 8192 GEMM prefers 4 (+1.6 ... +3.8 %) and so does the 16384-column w1|w3 GEMM (+1.7 %), everything between is flat
+// within 1 % and keeps 8.  (Powers of two - 4, 8 - are the worst choices for the K = 1024 shapes on both main loops.)
+static int pick_gm(int N, int K) { return K <= 1024 ? 5 : (K >= 8192 || N >= 8192) ? 4 : 8; }
 
 extern "C" int64_t mjv_gemm_workspace_bytes(void) { return 256L * 262144L; }
 
@@ -1050,7 +1051,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.m_base = 0;
   a.ws = nullptr;
   a.split = 1;
-  a.gm = g_gm > 0 ? g_gm : pick_gm(d->K);
+  a.gm = g_gm > 0 ? g_gm : pick_gm(d->N, d->K);
   a.rope_cos = d->rope_cos; a.rope_sin = d->rope_sin; a.rope_pos = d->rope_pos; a.rope_q = d->rope_q; a.rope_k = d->rope_k;
   a.rope_ldq = d->rope_ldq; a.rope_ldk = d->rope_ldk; a.rope_group = d->rope_group;
   a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;

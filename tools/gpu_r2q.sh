@@ -1,10 +1,3 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2q; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k gemm > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
-for i in 1 2; do python bench.py --no-latency > $O/bench$i.json 2> $O/bench.err; python - <<PY
-import json
-d=json.loads(open('gpurun_out/r2q/bench$i.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'])
-for k,v in sorted(d['kernels'].items(), key=lambda kv:-kv[1]['ms_per_step'])[:8]: print(f"{k:26s} {v['ms_per_step']:7.3f} {v.get('tflops')}")
-PY
-done
+MJV_BENCH_ROUNDS=6 timeout 900 python tools/gemm_bench.py 0 2003 2004 2005 2006 2007 2008 2010 2012 > $O/gb.log 2>&1; grep -v "^square\|nogelu\|amdgpu.ids" $O/gb.log | sed 's/ ms / /g; s/ TF\/s//g; s/tile20//g'
