@@ -339,6 +339,8 @@ def _rank_case_engineered(cuda, name, pairs_per_forward):
     enpz, emeta = load_golden(name.replace("rankset", "rankeng"))
     ref, keep, got = enpz["ref_bf16"], enpz["keep"], run["eng"]
     P = ref.shape[0]
+    assert got.shape[0] >= P
+    got = got[:P]      # (an engineered set may hold fewer pairs than the rank set it was cut from)
     f32, idx32 = enpz["ref_fp32"], enpz["fp32_pairs"]
     noise = (ref[idx32][..., 0] - f32[..., 0]).ravel()
     noise_rms = float(np.sqrt((noise ** 2).mean()))
