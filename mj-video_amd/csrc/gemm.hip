@@ -601,7 +601,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   // dead after group 1's phase-II reads (I_4t+3), refilled from I_4t+4 on.  K-tile t+1 is retired by every wave before the
   // barrier that ends its phase-II read segment (group 1: end of I_4t+3), one barrier before group 0 first reads it (I_4t+4).
   // (One phase per K-tile - all reads, 64 MFMAs, two barriers - fits in 250 VGPRs but needs the DMA issue and its retiring
-  // wait placed per M-group to stay race-free, and then runs 10-20 % slower than this.)
+  // wait placed per M-group to stay race-free, and then runs 10-20 % slower than this.  Giving the A halves one more barrier
+  // interval between issue and retire - group 0 retiring after its phase-II MFMAs, group 1 issuing at the head of its
+  // phase-II MFMA segment - measured 0 ... -4 %: the retiring wait is not what the loop waits for.)
   for (int t = 0; t < nk; ++t) {
     const char* abase = smem + ((t & 1) * 4 + a_half) * HALF_BYTES;
     const char* wbase = smem + ((t & 1) * 4 + w_half) * HALF_BYTES;
