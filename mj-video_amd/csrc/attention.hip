@@ -420,7 +420,10 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 // interleaved instruction by instruction with the softmax of tile t).  On this part the softmax's vector work and the
 // MFMAs of a SIMD take close to the SUM of their times in every arrangement tried (tools/micro/coissue*.hip), so the
 // levers that paid were the ones that remove work or traffic: XCD-aware placement, leaner staging addresses, scalar
-// control flow, heaviest-first causal order, the one-wave ragged block.
+// control flow, heaviest-first causal order, the one-wave ragged block.  Round 2: two K/V buffers in LDS with ONE barrier per
+// key tile instead of two (the lever that gave the GEMM main loop +2-7 %) is bit-identical and measures 0 % at D = 128
+// (same occupancy) and -4 % at D = 64 (three workgroups per CU instead of four): with several workgroups per CU the barrier
+// waits are already covered by the other workgroups' waves.
 
 int g_attn_variant = 0;
 
