@@ -567,6 +567,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   stage_half<3>(sp, 0, nk, smem, wave);
   stage_half<0>(sp, 1, nk, smem, wave);
   stage_half<1>(sp, 1, nk, smem, wave);
+  // the 128 accumulator registers are zeroed HERE, under the first K-tile's flight time: left alone, the compiler sinks the
+  // v_movs (256 of them: one set per side of the loop-entry branch) below the wait and the barriers, where they are 1-2 k
+  // exposed cycles per tile
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
   if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   MJV_BARRIER();
