@@ -552,6 +552,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
   };
   const unsigned long long t_start = stamp();
+  // bias of this lane's 4 x 4 output columns: requested before the first DMA (oldest in the in-order vmcnt queue, so the
+  // counted waits below mean what they meant), used in pass A - loaded there, each of the four loads was followed by its
+  // own s_waitcnt vmcnt(0): four dependent L2 round trips, 2 k of pass A's 2.6 k cycles
+  u32x2 braw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    braw[j] = u32x2{0u, 0u};
+    const int nl = wc * 64 + j * 16 + l4 * 4;
+    if (EPI != MJV_EPI_SILU_MUL && p.bias && n0 + nl < p.N) braw[j] = *(const u32x2*)(p.bias + n0 + nl);
+  }
   StagePtrs sp;
   init_stage_ptrs(sp, p, m0, n0, wave, lane);
   if constexpr (SPLIT) {
@@ -702,14 +712,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int nl = wc * 64 + j * 16 + l4 * 4;   // column inside the 256-wide weight tile
-    float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI != MJV_EPI_SILU_MUL && p.bias && n0 + nl < p.N) {
-      const u32x2 bb = *(const u32x2*)(p.bias + n0 + nl);
-      b4[0] = __uint_as_float(bb[0] << 16);
-      b4[1] = __uint_as_float(bb[0] & 0xffff0000u);
-      b4[2] = __uint_as_float(bb[1] << 16);
-      b4[3] = __uint_as_float(bb[1] & 0xffff0000u);
-    }
+    const u32x2 bb = braw[j];
+    const float b4[4] = {__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                         __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
     if (EPI == MJV_EPI_SILU_MUL && (j & 1)) continue;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -822,11 +827,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const bool plain = !p.out_rows && p.out_group <= 0 && p.res_mod <= 0;
     u16* crow = p.C + (long)(p.m_base + m0 + ml0) * p.ldc + n;
     const long cstep = (long)ROWS_PER_PASS * p.ldc;
+    // all of this thread's rows out of the staged tile first (the accumulator registers are free): one row at a time the
+    // loop was {ds_read, s_waitcnt lgkmcnt(0), store} sixteen times, a full LDS latency per row
+    u32x4 vals[PASSES];
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) vals[it] = *(const u32x4*)(etile + (it * ROWS_PER_PASS + ml0) * EPI_PITCH + c8 * 2);
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
       const int ml = it * ROWS_PER_PASS + ml0;
       if (m0 + ml >= p.M || n >= nlim) continue;
-      u32x4 val = *(const u32x4*)(etile + ml * EPI_PITCH + c8 * 2);
+      u32x4 val = vals[it];
       if constexpr (EPI == MJV_EPI_SCALE_RES) {
         float v[8], rs[8];
         unpack8(val, v);
