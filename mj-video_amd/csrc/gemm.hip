@@ -562,6 +562,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int nl = wc * 64 + j * 16 + l4 * 4;
     if (EPI != MJV_EPI_SILU_MUL && p.bias && n0 + nl < p.N) braw[j] = *(const u32x2*)(p.bias + n0 + nl);
   }
+  // (LayerScale vector of this thread's pass-B columns: same treatment)
+  constexpr int OUT_COLS_E = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
+  u32x4 scraw = {0u, 0u, 0u, 0u};
+  if constexpr (EPI == MJV_EPI_SCALE_RES) {
+    const int ne = n0 + (tid % (OUT_COLS_E / 8)) * 8;
+    if (p.scale && ne < p.N) scraw = *(const u32x4*)(p.scale + ne);
+  }
   StagePtrs sp;
   init_stage_ptrs(sp, p, m0, n0, wave, lane);
   if constexpr (SPLIT) {
@@ -646,6 +653,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     MJV_BARRIER();
   }
   if (wr == 0) MJV_BARRIER();  // matches the stagger barrier of the second M-group
+  // every load of this wave has landed (the last K-tile's vmcnt(0) above is inline assembly, which the compiler's wait-count
+  // pass does not read): said once more in a form it does read, so that the first use of the bias registers in pass A does
+  // not get a conservative vmcnt(0) of its own - that one would also wait for the residual rows requested just below, whose
+  // flight time pass A is there to cover
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
   const unsigned long long t_main = stamp();
 #undef MJV_LOAD_A
 #undef MJV_LOAD_W
@@ -697,15 +709,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   u32x4 rsv[(EPI == MJV_EPI_SCALE_RES) ? PASSES : 1];
   float sc[8];
   if constexpr (EPI == MJV_EPI_SCALE_RES) {
-    if (p.scale && n < nlim) unpack8(*(const u32x4*)(p.scale + n), sc);
+    unpack8(scraw, sc);
+    if (p.res_mod > 0) {   // uniform: residual rows repeat with a period (position embeddings)
 #pragma unroll
-    for (int it = 0; it < PASSES; ++it) {
-      const int ml = it * ROWS_PER_PASS + ml0;
-      rsv[it] = u32x4{0u, 0u, 0u, 0u};
-      if (m0 + ml < p.M && n < nlim) {
-        const int m = p.m_base + m0 + ml;
-        const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;   // uniform branch
-        rsv[it] = *(const u32x4*)(p.res + rrow * p.ldr + n);
+      for (int it = 0; it < PASSES; ++it) {
+        const int ml = it * ROWS_PER_PASS + ml0;
+        rsv[it] = u32x4{0u, 0u, 0u, 0u};
+        if (m0 + ml < p.M && n < nlim) {
+          const int m = p.m_base + m0 + ml;
+          rsv[it] = *(const u32x4*)(p.res + (long)(p.res_off + (m % p.res_mod)) * p.ldr + n);
+        }
+      }
+    } else {               // residual row == output row: one base pointer, constant row step
+      const u16* rp = p.res + (long)(p.m_base + m0 + ml0) * p.ldr + n;
+      const long rstep = (long)ROWS_PER_PASS * p.ldr;
+#pragma unroll
+      for (int it = 0; it < PASSES; ++it) {
+        rsv[it] = u32x4{0u, 0u, 0u, 0u};
+        if (m0 + it * ROWS_PER_PASS + ml0 < p.M && n < nlim) rsv[it] = *(const u32x4*)(rp + it * rstep);
       }
     }
   }
