@@ -143,6 +143,89 @@ MJV_DEV void store_silu(const GemmArgs& p, const f32x4& g, const f32x4& u, long 
   *(u32x2*)(p.C + orow * p.ldc + oc) = v;
 }
 
+// Epilogue of the small kernels for an NI x NJ block of 16x16 accumulator fragments of one thread (fragment (i, j): output
+// row mrel[i] of the launch, columns ncol[j] .. ncol[j] + 3).  Same arithmetic and rounding points as store_frag, but every
+// global load of the block - output-row map, bias, LayerScale, residual - is issued before the first use, from clamped
+// (always valid) addresses: fragment by fragment behind row / column conditions, each load got a branch and an
+// s_waitcnt vmcnt(0) of its own, three to four dependent L2 round trips per fragment, sixteen fragments per thread.
+template <int EPI, int NI, int NJ>
+MJV_DEV void store_frags(const GemmArgs& p, const f32x4* acc /* [NI][NJ] */, const int (&mrel)[NI], const int (&ncol)[NJ]) {
+  static_assert(EPI != MJV_EPI_SILU_MUL, "SiLU pairs go through store_silu");
+  int mc[NI], nc[NJ];
+  long orow[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) mc[i] = p.m_base + (mrel[i] < p.M ? mrel[i] : p.M - 1);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) nc[j] = ncol[j] < p.N ? ncol[j] : p.N - 4;
+  if (p.out_rows) {
+    int t[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) t[i] = p.out_rows[mc[i]];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) orow[i] = t[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) orow[i] = out_row_of(p, mc[i]);
+  }
+  u32x2 bb[NJ], ss[NJ], rr[NI][NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) bb[j] = ss[j] = u32x2{0u, 0u};
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bb[j] = *(const u32x2*)(p.bias + nc[j]);
+  }
+  if constexpr (EPI == MJV_EPI_SCALE_RES) {
+    if (p.scale) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) ss[j] = *(const u32x2*)(p.scale + nc[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const long rrow = p.res_mod > 0 ? (long)(p.res_off + (mc[i] % p.res_mod)) : (long)mc[i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) rr[i][j] = *(const u32x2*)(p.res + rrow * p.ldr + nc[j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    if (mrel[i] >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (ncol[j] >= p.N) continue;
+      const f32x4 a = acc[i * NJ + j];
+      float v[4] = {a[0], a[1], a[2], a[3]};
+      if (p.bias) {
+        v[0] += __uint_as_float(bb[j][0] << 16);
+        v[1] += __uint_as_float(bb[j][0] & 0xffff0000u);
+        v[2] += __uint_as_float(bb[j][1] << 16);
+        v[3] += __uint_as_float(bb[j][1] & 0xffff0000u);
+      }
+      if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_lut(rbf(v[r]), g_gelu_table);
+      } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if constexpr (EPI == MJV_EPI_SCALE_RES) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        if (p.scale) {
+          v[0] = rbf(v[0] * __uint_as_float(ss[j][0] << 16));
+          v[1] = rbf(v[1] * __uint_as_float(ss[j][0] & 0xffff0000u));
+          v[2] = rbf(v[2] * __uint_as_float(ss[j][1] << 16));
+          v[3] = rbf(v[3] * __uint_as_float(ss[j][1] & 0xffff0000u));
+        }
+        v[0] += __uint_as_float(rr[i][j][0] << 16);
+        v[1] += __uint_as_float(rr[i][j][0] & 0xffff0000u);
+        v[2] += __uint_as_float(rr[i][j][1] << 16);
+        v[3] += __uint_as_float(rr[i][j][1] & 0xffff0000u);
+      }
+      const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *(u32x2*)(p.C + orow[i] * p.ldc + ncol[j]) = o;
+    }
+  }
+}
+
 MJV_DEV void tile_of_vblock(const GemmArgs& p, int nwg, int b, int& tm, int& tn);
 MJV_DEV void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_vblock(p, gridDim.x, blockIdx.x, tm, tn); }
 MJV_DEV void tile_of_vblock(const GemmArgs& p, const int nwg, const int b, int& tm, int& tn) {
@@ -253,27 +336,26 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
     return;
   }
 
+  if constexpr (EPI == MJV_EPI_SILU_MUL) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int mrel = m0 + wm * 64 + i * 16 + l15;
-    if (mrel >= p.M) continue;
-    const int m = p.m_base + mrel;
-    const long orow = out_row_of(p, m);
-    if constexpr (EPI == MJV_EPI_SILU_MUL) {
+    for (int i = 0; i < 4; ++i) {
+      const int mrel = m0 + wm * 64 + i * 16 + l15;
+      if (mrel >= p.M) continue;
+      const long orow = out_row_of(p, p.m_base + mrel);
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {
         const int n = n0 + wn * 64 + j * 16 + l4 * 4;
         if (n >= p.N) continue;
         store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4);
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + l4 * 4;
-        if (n >= p.N) continue;
-        store_frag<EPI>(p, acc[i][j], m, orow, n);
-      }
     }
+  } else {
+    int mrel[4], ncol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mrel[i] = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ncol[j] = n0 + wn * 64 + j * 16 + l4 * 4;
+    store_frags<EPI, 4, 4>(p, &acc[0][0], mrel, ncol);
   }
 }
 
@@ -300,27 +382,26 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] += im2[(i * 4 + j) * 256];
   }
+  if constexpr (EPI == MJV_EPI_SILU_MUL) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int mrel = m0 + wm * 64 + i * 16 + l15;
-    if (mrel >= p.M) continue;
-    const int m = p.m_base + mrel;
-    const long orow = out_row_of(p, m);
-    if constexpr (EPI == MJV_EPI_SILU_MUL) {
+    for (int i = 0; i < 4; ++i) {
+      const int mrel = m0 + wm * 64 + i * 16 + l15;
+      if (mrel >= p.M) continue;
+      const long orow = out_row_of(p, p.m_base + mrel);
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {
         const int n = n0 + wn * 64 + j * 16 + l4 * 4;
         if (n >= p.N) continue;
         store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4);
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + l4 * 4;
-        if (n >= p.N) continue;
-        store_frag<EPI>(p, acc[i][j], m, orow, n);
-      }
     }
+  } else {
+    int mrel[4], ncol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mrel[i] = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ncol[j] = n0 + wn * 64 + j * 16 + l4 * 4;
+    store_frags<EPI, 4, 4>(p, &acc[0][0], mrel, ncol);
   }
 }
 }  // namespace t128
@@ -414,21 +495,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     }
   }
   const int mrel = m0 + wave * 16 + l15;
-  if (mrel >= p.M) return;
-  const int m = p.m_base + mrel;
-  const long orow = out_row_of(p, m);
   if constexpr (EPI == MJV_EPI_SILU_MUL) {
+    if (mrel >= p.M) return;
+    const long orow = out_row_of(p, p.m_base + mrel);
 #pragma unroll
     for (int j = 0; j < NJ; j += 2) {
       const int n = n0 + j * 16 + l4 * 4;
       if (n < p.N) store_silu(p, acc[j], acc[j + 1], orow, n0 / 2 + (j / 2) * 16 + l4 * 4);
     }
   } else {
+    const int mr[1] = {mrel};
+    int ncol[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + j * 16 + l4 * 4;
-      if (n < p.N) store_frag<EPI>(p, acc[j], m, orow, n);
-    }
+    for (int j = 0; j < NJ; ++j) ncol[j] = n0 + j * 16 + l4 * 4;
+    store_frags<EPI, 1, NJ>(p, &acc[0], mr, ncol);
   }
 }
 }  // namespace t64
@@ -797,11 +877,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       const int dcol = c8 & 127;                       // column inside the head
       const bool is_v = within == p.rope_group + 1, is_k = within == p.rope_group;
       const bool col_ok = n < nlim;
+      // unconditional loads from clamped rows: behind a per-row condition every one of the 16 loads got its own branch and
+      // its own s_waitcnt vmcnt(0) - sixteen dependent L2 round trips before the barrier
       int posv[PASSES];
+      const int* pos_base = p.rope_pos + (long)p.m_base;
 #pragma unroll
       for (int it = 0; it < PASSES; ++it) {
-        const int ml = it * ROWS_PER_PASS + ml0;
-        posv[it] = (!is_v && col_ok && m0 + ml < p.M) ? p.rope_pos[(long)p.m_base + m0 + ml] : 0;
+        const int mr = m0 + it * ROWS_PER_PASS + ml0;
+        posv[it] = pos_base[mr < p.M ? mr : p.M - 1];
       }
       __syncthreads();
       const float sgn = dcol < 64 ? -1.f : 1.f;        // rotate_half: (-x2, x1)
@@ -914,10 +997,9 @@ __global__ __launch_bounds__(512) void splitk_finish256_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j) fr[j] += img[(long)sl * (32 * 512) + (i * 4 + j) * 512];
   }
   const int mrel = m0 + wr * 128 + i * 16 + l15;
-  if (mrel >= p.M) return;
-  const int m = p.m_base + mrel;
-  const long orow = out_row_of(p, m);
   if constexpr (EPI == MJV_EPI_SILU_MUL) {
+    if (mrel >= p.M) return;
+    const long orow = out_row_of(p, p.m_base + mrel);
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
       const int n = n0 + wc * 64 + j * 16 + l4 * 4;
@@ -925,12 +1007,11 @@ __global__ __launch_bounds__(512) void splitk_finish256_kernel(GemmArgs p) {
       store_silu(p, fr[j], fr[j + 1], orow, n0 / 2 + wc * 32 + (j / 2) * 16 + l4 * 4);
     }
   } else {
+    const int mr[1] = {mrel};
+    int ncol[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + l4 * 4;
-      if (n >= p.N) continue;
-      store_frag<EPI>(p, fr[j], m, orow, n);
-    }
+    for (int j = 0; j < 4; ++j) ncol[j] = n0 + wc * 64 + j * 16 + l4 * 4;
+    store_frags<EPI, 1, 4>(p, &fr[0], mr, ncol);
   }
 }
 
