@@ -651,6 +651,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   }
   StagePtrs sp;
   init_stage_ptrs(sp, p, m0, n0, wave, lane);
+  if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+    // the GELU table (13 KB) goes to its LDS region past the pipeline buffers by LDS-DMA, issued before the first K-tile
+    // (older in the vmcnt queue than everything the counted waits below count): copied at the head of the epilogue it cost
+    // a global round trip and a barrier per tile
+    static_assert(MJV_GELU_TABLE_LEN % 8 == 0 && MJV_GELU_TABLE_LEN / 8 <= 1024, "two 16-byte chunks per thread cover the table");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int chunk = (i * 8 + wave) * 64 + lane;
+      if (chunk < MJV_GELU_TABLE_LEN / 8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const u32x4*)g_gelu_table + chunk),
+                                         (__attribute__((address_space(3))) void*)(smem + EPI_TILE_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
+    }
+  }
   if constexpr (SPLIT) {
 #pragma unroll
     for (int which = 0; which < 4; ++which)
@@ -769,10 +782,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   //         K = 1024 GEMMs at half speed).
   char* etile = smem;
   u16* gtab = (u16*)(smem + EPI_TILE_BYTES);
-  if constexpr (EPI == MJV_EPI_BIAS_GELU) {
-    for (int c = tid; c < MJV_GELU_TABLE_LEN / 8; c += 512) ((u32x4*)gtab)[c] = ((const u32x4*)g_gelu_table)[c];
-    __syncthreads();
-  }
+  // (the GELU table was copied to its LDS region - beyond the pipeline buffers - by the prologue's first DMA instructions)
   constexpr int OUT_COLS = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
   // pass B geometry: 32 (16 for SiLU) lanes x 16 B = one output row per pass
   constexpr int LANES_PER_ROW = OUT_COLS / 8;          // 16-B chunks per output row
