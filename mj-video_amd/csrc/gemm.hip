@@ -827,6 +827,50 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const float b4[4] = {__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
                          __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
     if (EPI == MJV_EPI_SILU_MUL && (j & 1)) continue;
+    if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+      // GELU by table, a whole column group (8 fragments = 32 elements per lane) at a time: the indices of all 32 first, ONE
+      // wave-wide range test, then 32 LDS gathers in flight together.  Fragment by fragment (round 2, first form) every
+      // quad of gathers was followed by its own s_waitcnt lgkmcnt(0) and its own wave vote: 32 exposed LDS latencies per lane.
+      // Fast path = every element of every lane of the wave inside the table (|x| in [2^-23, 5.56): all but one activation
+      // in ~10^7 for unit-scale inputs): magnitude - LO + sign * R indexes the table directly; otherwise the general form
+      // (x/2 below the table, x or -0 above).
+      unsigned ubs[8][4], idx[8][4];
+      bool all_in = true;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ubs[i][r] = __float_as_uint(rbf(acc[i][j][r] + b4[r]));
+          const unsigned rel = ((ubs[i][r] >> 16) & 0x7fffu) - MJV_GELU_LO;
+          all_in = all_in && (rel < (unsigned)MJV_GELU_R);
+          idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_R;
+        }
+      if (__all(all_in)) {
+        unsigned t[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[i][r] = gtab[idx[i][r]];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ml = wr * 128 + i * 16 + l15;
+          // table entries are bf16 bit patterns: two of them side by side are the packed pair as it is
+          const u32x2 o = {t[i][0] | (t[i][1] << 16), t[i][2] | (t[i][3] << 16)};
+          *(u32x2*)(etile + ml * EPI_PITCH + nl * 2) = o;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ml = wr * 128 + i * 16 + l15;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_lut(__uint_as_float(ubs[i][r]), gtab);
+          const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+          *(u32x2*)(etile + ml * EPI_PITCH + nl * 2) = o;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int ml = wr * 128 + i * 16 + l15;
@@ -839,29 +883,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + b4[r];
-        if constexpr (EPI == MJV_EPI_BIAS_GELU) {
-          // fast path when every element of every lane of the wave lies inside the table (|x| in [2^-23, 5.56): all but
-          // one activation in ~10^7 for unit-scale inputs): magnitude - LO + sign * R indexes the table directly, 8 vector
-          // instructions per element instead of 16; otherwise the general form (x/2 below, x or -0 above the table)
-          unsigned ub[4], rel[4];
-          bool all_in = true;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ub[r] = __float_as_uint(rbf(v[r]));
-            rel[r] = ((ub[r] >> 16) & 0x7fffu) - MJV_GELU_LO;
-            all_in = all_in && (rel[r] < (unsigned)MJV_GELU_R);
-          }
-          if (__all(all_in)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const unsigned idx = rel[r] + (ub[r] >> 31) * (unsigned)MJV_GELU_R;
-              v[r] = __uint_as_float((unsigned)gtab[idx] << 16);
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_lut(__uint_as_float(ub[r]), gtab);
-          }
-        } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
+        if constexpr (EPI == MJV_EPI_BIAS_RELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
