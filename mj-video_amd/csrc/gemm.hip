@@ -96,44 +96,6 @@ MJV_DEV long out_row_of(const GemmArgs& p, int m) {
   return m;
 }
 
-// one 16x16 accumulator fragment: this lane holds output row m, columns n .. n+3
-template <int EPI>
-MJV_DEV void store_frag(const GemmArgs& p, const f32x4& acc, int m, long orow, int n) {
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  if (p.bias) {
-    const u32x2 bb = *(const u32x2*)(p.bias + n);
-    v[0] += __uint_as_float(bb[0] << 16);
-    v[1] += __uint_as_float(bb[0] & 0xffff0000u);
-    v[2] += __uint_as_float(bb[1] << 16);
-    v[3] += __uint_as_float(bb[1] & 0xffff0000u);
-  }
-  if constexpr (EPI == MJV_EPI_BIAS_GELU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = gelu_lut(rbf(v[r]), g_gelu_table);
-  } else if constexpr (EPI == MJV_EPI_BIAS_RELU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-  } else if constexpr (EPI == MJV_EPI_SCALE_RES) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-    if (p.scale) {
-      const u32x2 ss = *(const u32x2*)(p.scale + n);
-      v[0] = rbf(v[0] * __uint_as_float(ss[0] << 16));
-      v[1] = rbf(v[1] * __uint_as_float(ss[0] & 0xffff0000u));
-      v[2] = rbf(v[2] * __uint_as_float(ss[1] << 16));
-      v[3] = rbf(v[3] * __uint_as_float(ss[1] & 0xffff0000u));
-    }
-    const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;
-    const u32x2 rr = *(const u32x2*)(p.res + rrow * p.ldr + n);
-    v[0] += __uint_as_float(rr[0] << 16);
-    v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-    v[2] += __uint_as_float(rr[1] << 16);
-    v[3] += __uint_as_float(rr[1] & 0xffff0000u);
-  }
-  const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-  *(u32x2*)(p.C + orow * p.ldc + n) = o;
-}
-
 // SiLU-mul: gate fragment (weight rows n..n+3 of a w1 block) and the matching up fragment (w3 block)
 MJV_DEV void store_silu(const GemmArgs& p, const f32x4& g, const f32x4& u, long orow, int oc) {
   float o[4];
@@ -144,9 +106,9 @@ MJV_DEV void store_silu(const GemmArgs& p, const f32x4& g, const f32x4& u, long 
 }
 
 // Epilogue of the small kernels for an NI x NJ block of 16x16 accumulator fragments of one thread (fragment (i, j): output
-// row mrel[i] of the launch, columns ncol[j] .. ncol[j] + 3).  Same arithmetic and rounding points as store_frag, but every
+// row mrel[i] of the launch, columns ncol[j] .. ncol[j] + 3).  One 16x16 fragment: the lane holds output row m, columns n .. n+3.  Every
 // global load of the block - output-row map, bias, LayerScale, residual - is issued before the first use, from clamped
-// (always valid) addresses: fragment by fragment behind row / column conditions, each load got a branch and an
+// (always valid) addresses: fragment by fragment behind row / column conditions (round 1), each load got a branch and an
 // s_waitcnt vmcnt(0) of its own, three to four dependent L2 round trips per fragment, sixteen fragments per thread.
 template <int EPI, int NI, int NJ>
 MJV_DEV void store_frags(const GemmArgs& p, const f32x4* acc /* [NI][NJ] */, const int (&mrel)[NI], const int (&ncol)[NJ]) {
