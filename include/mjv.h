@@ -135,7 +135,8 @@ int mjv_attention_bf16(const mjv_attn_desc* d, void* stream);
 /* timing-experiment selector (tools/attn_bench.py; process-wide, never needed for results): 0 = production; on the two
  * production shapes (D = 64 non-causal with a power-of-two scale, D = 128 causal mode 1) 1 = K/V staged once (no
  * barriers / LDS stores / global loads after the first tile), 2 = softmax removed, 3 = MFMAs removed - wrong results by
- * construction, they attribute the kernel's time.  Other values return MJV_E_ARG.
+ * construction, they attribute the kernel's time; 4 = the register-staged kernel for every sequence length (correct
+ * results; A/B against the LDS-DMA staging that the automatic choice uses for max_seqlen <= 4096).  Other values return MJV_E_ARG.
  * max_seqlen MUST be >= the longest sequence of cu_seqlens: query rows beyond it are not computed (their O rows are
  * left untouched). */
 int mjv_attention_set_variant(int32_t variant);

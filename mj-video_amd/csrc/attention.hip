@@ -1,8 +1,9 @@
 // Flash-style attention for gfx950 over packed variable-length sequences.
 //
 // One workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries.  K/V tiles of
-// 64 keys are staged through LDS (register staged, padded pitches: K rows are read row-wise with
-// ds_read_b128, V rows column-wise with ds_read_b64_tr_b16).
+// 64 keys go global -> LDS by LDS-DMA into two unpadded buffers with a source-side chunk swizzle (K rows are
+// read row-wise with ds_read_b128, V rows column-wise with ds_read_b64_tr_b16, both conflict-free); the
+// register-staged, row-padded single-buffer form of round 1 is kept as the DMA = false instantiation.
 //
 // QK^T is computed SWAPPED, S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows, B = Q^T), so a lane
 // owns ONE query (MFMA column) and its 16 accumulator registers are 16 keys: row max / row sum are
@@ -12,6 +13,7 @@
 // softmax rescale is a per-lane scalar multiply.
 #include "mjv_common.h"
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -101,12 +103,21 @@ MJV_DEV float round_score(float a, float scale) {
 // VAR: 0 = production.  Timing experiments (wrong results by construction, tools/attn_bench.py only; selected with
 // mjv_attention_set_variant): 1 = K/V staged once (no barriers, no LDS stores, no global loads after tile 0),
 // 2 = softmax removed (P = bf16(S)), 3 = MFMAs removed (LDS reads and the softmax kept).
-template <int D, bool CAUSAL, int RM, int VAR = 0>
+// DMA = true (production since round 2 for sequences of up to 4096 keys): K / V tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write) into
+// TWO unpadded buffers (one barrier per key tile, 32 / 64 KB per workgroup: same occupancy as the padded single buffer);
+// bit-identical to the register-staged form (DMA = false: variant 4 and the timing variants 1-3), +2 % at both head sizes; bank conflicts are removed by a chunk swizzle applied on the DMA's source
+// address instead of by row padding: 16-byte chunk c of K row r sits at chunk c ^ sK(r), sK = (r >> 1) & 7 (D = 64) /
+// r & 15 (D = 128); of V row r at c ^ sV(r), sV = ((r >> 1) & 1) * 4 / (r & 3) * 4 - both conflict-free for the lane groups
+// of ds_read_b128 (K, row-wise) and ds_read_b64_tr_b16 (V, transposed) by exhaustive check of the access patterns below.
+template <int D, bool CAUSAL, int RM, int VAR = 0, bool DMA = false>
 __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p) {
   using C = Cfg<D>;
-  __shared__ __attribute__((aligned(16))) char smem[C::K_BYTES + C::V_BYTES];
+  constexpr int PK = DMA ? D * 2 : C::KP;   // row pitches in bytes
+  constexpr int PV = DMA ? D * 2 : C::VP;
+  constexpr int KBYTES = KB * PK, VBYTES = KB * PV, TB = KBYTES + VBYTES;
+  __shared__ __attribute__((aligned(16))) char smem[DMA ? 2 * TB : TB];
   char* Ks = smem;
-  char* Vs = smem + C::K_BYTES;
+  char* Vs = smem + KBYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every branch on it below is wave-uniform
@@ -180,13 +191,13 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
       vreg[c] = *(const u32x4*)(v_seq + vo[c]);
     }
   };
-  char* const k_st = Ks + st_row * C::KP + st_ch * 16;
-  char* const v_st = Vs + st_row * C::VP + st_ch * 16;
+  char* const k_st = Ks + st_row * PK + st_ch * 16;
+  char* const v_st = Vs + st_row * PV + st_ch * 16;
   auto store_tile = [&]() {
 #pragma unroll
     for (int c = 0; c < C::LOADS; ++c) {
-      *(u32x4*)(k_st + c * ROWS_PER_LOAD * C::KP) = kreg[c];
-      *(u32x4*)(v_st + c * ROWS_PER_LOAD * C::VP) = vreg[c];
+      *(u32x4*)(k_st + c * ROWS_PER_LOAD * PK) = kreg[c];
+      *(u32x4*)(v_st + c * ROWS_PER_LOAD * PV) = vreg[c];
     }
   };
 
@@ -213,15 +224,29 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
       for (int c = 0; c < 2; ++c) {
         const int idx = lane + (c0 + c) * 64;
         const int row = idx / C::CHUNKS, ch = idx % C::CHUNKS;
-        *(u32x4*)(Ks + row * C::KP + ch * 16) = a[c];
-        *(u32x4*)(Vs + row * C::VP + ch * 16) = b[c];
+        *(u32x4*)(Ks + row * PK + ch * 16) = a[c];
+        *(u32x4*)(Vs + row * PV + ch * 16) = b[c];
       }
     }
   };
 
   // prefetch = true: this wave's share of the NEXT tile's global loads is issued after the QK^T MFMAs (the staging
   // registers are then free while the K fragments are read, and still have the softmax and the PV product to land)
-  auto tile_math = [&](int kt, bool prefetch) {
+  // DMA: per-lane LDS byte offsets of the K fragments (row l31, chunk (hi + 2 ks) ^ sK) and of the V fragments
+  // (row 4 hi + trow, chunk ((i >> 2) * 4 + g16 * 2 + (tcol >> 3)) ^ sV): the swizzle terms are lane constants
+  int koff[D / 16], vboff[D / 32];
+  if constexpr (DMA) {
+    const int ksw = (D == 64) ? ((l31 >> 1) & 7) : (l31 & 15);
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) koff[ks] = l31 * PK + (((hi + 2 * ks) ^ ksw) << 4);
+    const int li = lane & 15, g16 = (lane >> 4) & 1, trow = li >> 2, tcol = 4 * (li & 3);
+    const int svl = (D == 64) ? (((trow >> 1) & 1) * 4) : (trow * 4);
+#pragma unroll
+    for (int g = 0; g < D / 32; ++g)
+      vboff[g] = (4 * hi + trow) * PV + (((g * 4 + g16 * 2 + (tcol >> 3)) ^ svl) << 4) + (tcol & 7) * 2;
+  }
+  auto tile_math = [&](int kt, bool prefetch, auto bufc) {
+    constexpr int BOFF = decltype(bufc)::value * TB;   // byte offset of the LDS buffer this tile sits in (DMA: 0 / TB)
     const int k0 = kt * KB;
     // wave-uniform: tile entirely above this wave's diagonal, or a wave without a query (ragged last q-block): it only
     // helps staging K/V and keeps the barriers balanced
@@ -236,10 +261,11 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
     f32x16 sacc[2];
     if constexpr (D == 128) {
       constexpr int N_QK = 2 * (D / 16), AHEAD = 3, RING = 4;
-      const char* kp = Ks + l31 * C::KP + hi * 16;
+      const char* kp = Ks + l31 * PK + hi * 16;
       bf16x8 kr[RING];
       auto read_k = [&](int i, bf16x8& f) {   // i = (D / 16) * t2 + ks
-        f = *(const bf16x8*)(kp + (i / (D / 16)) * 32 * C::KP + (i % (D / 16)) * 32);
+        if constexpr (DMA) f = *(const bf16x8*)(Ks + BOFF + (i / (D / 16)) * 32 * PK + koff[i % (D / 16)]);
+        else f = *(const bf16x8*)(kp + (i / (D / 16)) * 32 * PK + (i % (D / 16)) * 32);
       };
 #pragma unroll
       for (int i = 0; i < AHEAD; ++i) read_k(i, kr[i % RING]);
@@ -265,10 +291,10 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
       for (int t2 = 0; t2 < 2; ++t2) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[t2][r] = 0.f;
-        const char* kp = Ks + (t2 * 32 + l31) * C::KP + hi * 16;
+        const char* kp = Ks + (t2 * 32 + l31) * PK + hi * 16;
 #pragma unroll
         for (int ks = 0; ks < D / 16; ++ks) {
-          const bf16x8 kf = *(const bf16x8*)(kp + ks * 32);
+          const bf16x8 kf = DMA ? *(const bf16x8*)(Ks + BOFF + t2 * 32 * PK + koff[ks]) : *(const bf16x8*)(kp + ks * 32);
           if constexpr (VAR == 3) {
             asm volatile("" ::"v"(kf));
             sacc[t2][ks] += (float)lane * 1e-3f;
@@ -354,14 +380,14 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
       const int g16 = (lane >> 4) & 1;     // which 16-column block of the 32-wide d tile
       const int li = lane & 15;
       const int trow = li >> 2, tcol = 4 * (li & 3);
-      const char* vbase = Vs + (4 * hi + trow) * C::VP + (g16 * 16 + tcol) * 2;
+      const char* vbase = Vs + (4 * hi + trow) * PV + (g16 * 16 + tcol) * 2;
       constexpr int N_PV = 4 * (D / 32), AHEAD = 3, RING = 4;
       bf16x8 fr[RING];
       auto read_v = [&](int i, bf16x8& f) {   // i = 4 * dt + 2 * t2 + s2
-        const char* vp = vbase + (i & 3) * 16 * C::VP + (i >> 2) * 64;
+        const char* vp = DMA ? Vs + BOFF + vboff[i >> 2] + (i & 3) * 16 * PV : vbase + (i & 3) * 16 * PV + (i >> 2) * 64;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
         const s16x4 hi4 =
-            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * C::VP));
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * PV));
         const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
         f = __builtin_bit_cast(bf16x8, v8);
       };
@@ -382,10 +408,78 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
     }
   };
 
-  if (solo) {
+  using Buf0 = std::integral_constant<int, 0>;
+  using Buf1 = std::integral_constant<int, 1>;
+  if constexpr (DMA) {
+    // this wave's LDS-DMA share of a tile: slot = 16-byte LDS slot of the unpadded tile image, NI slots per operand
+    constexpr int CH = D / 8, NI = KB * CH / 256;
+    auto src_off = [&](int slot, int row0, long ld, bool is_k) -> unsigned {
+      const int row = slot / CH, cl = slot % CH;
+      const int sw = is_k ? ((D == 64) ? ((row >> 1) & 7) : (row & 15)) : ((D == 64) ? (((row >> 1) & 1) * 4) : ((row & 3) * 4));
+      int gr = row0 + row;
+      gr = gr < len ? gr : len - 1;                      // rows past the sequence end: any valid row (masked later)
+      return (unsigned)(gr * (int)ld + ((cl ^ sw) * 8)) * 2u;
+    };
+    unsigned kso[NI], vso[NI];                            // whole tiles: offsets relative to the tile's first row
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int slot = (j * 4 + wave) * 64 + lane;
+      const int row = slot / CH, cl = slot % CH;
+      const int sk = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+      const int sv = (D == 64) ? (((row >> 1) & 1) * 4) : ((row & 3) * 4);
+      kso[j] = (unsigned)(row * (int)p.ldk + ((cl ^ sk) * 8)) * 2u;
+      vso[j] = (unsigned)(row * (int)p.ldv + ((cl ^ sv) * 8)) * 2u;
+    }
+    auto issue = [&](int kt, int boff, int w_lo, int w_hi) {   // DMA shares of waves w_lo .. w_hi - 1 (the solo wave issues all four)
+      char* kdst = smem + boff;
+      char* vdst = smem + boff + KBYTES;
+      const bool whole = kt * KB + KB <= len;
+      for (int w = w_lo; w < w_hi; ++w) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          unsigned ko, vo;
+          if (whole && w == wave) {
+            ko = kso[j] + (unsigned)(kt * KB) * (unsigned)p.ldk * 2u;
+            vo = vso[j] + (unsigned)(kt * KB) * (unsigned)p.ldv * 2u;
+          } else {
+            const int slot = (j * 4 + w) * 64 + lane;
+            ko = src_off(slot, kt * KB, p.ldk, true);
+            vo = src_off(slot, kt * KB, p.ldv, false);
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k_seq + ko),
+                                           (__attribute__((address_space(3))) void*)(kdst + (j * 4 + w) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(v_seq + vo),
+                                           (__attribute__((address_space(3))) void*)(vdst + (j * 4 + w) * 1024), 16, 0, 0);
+        }
+      }
+    };
+    if (solo) {
+      for (int kt = 0; kt < n_tiles; ++kt) {
+        issue(kt, 0, 0, 4);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): one wave, its own LDS operations are in order
+        tile_math(kt, false, Buf0{});
+      }
+    } else {
+      issue(0, 0, wave, wave + 1);
+      for (int kt = 0; kt < n_tiles; kt += 2) {
+        // tile kt is in buffer 0: every wave's share has landed after the wait + barrier, and every wave has finished tile
+        // kt - 1 (buffer 1), which the next DMA overwrites
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (kt + 1 < n_tiles) issue(kt + 1, TB, wave, wave + 1);
+        tile_math(kt, false, Buf0{});
+        if (kt + 1 < n_tiles) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          __syncthreads();
+          if (kt + 2 < n_tiles) issue(kt + 2, 0, wave, wave + 1);
+          tile_math(kt + 1, false, Buf1{});
+        }
+      }
+    }
+  } else if (solo) {
     for (int kt = 0; kt < n_tiles; ++kt) {
       stage_solo(kt);
-      tile_math(kt, false);
+      tile_math(kt, false, Buf0{});
     }
   } else {
     load_tile(0);
@@ -395,7 +489,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
         store_tile();
         __syncthreads();
       }
-      tile_math(kt, VAR != 1 && kt + 1 < n_tiles);
+      tile_math(kt, VAR != 1 && kt + 1 < n_tiles, Buf0{});
     }
   }
 
@@ -440,17 +534,28 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
     if (g_attn_variant == 1) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 1>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
     if (g_attn_variant == 2) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 2>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
     if (g_attn_variant == 3) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 3>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
+    if (g_attn_variant == 4) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 0, false>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
   }
-  if (a.round_mode == 1) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV>), grid, dim3(256), 0, s, a);
-  else if (pow2) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_POW2>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_MUL>), grid, dim3(256), 0, s, a);
+  // LDS-DMA staging up to 4096 keys per sequence (measured +2 ... +3 % at 1025 / 2186, 0 at 2048 non-causal); beyond that
+  // the register-staged form is the faster one (causal, 8192 keys: 0.64 vs 0.66 ms), so the long-context config keeps it
+  const bool dma = max_seqlen <= 4096;
+  if (a.round_mode == 1) {
+    if (dma) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV, 0, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV, 0, false>), grid, dim3(256), 0, s, a);
+  } else if (pow2) {
+    if (dma) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_POW2, 0, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_POW2, 0, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (dma) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_MUL, 0, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_MUL, 0, false>), grid, dim3(256), 0, s, a);
+  }
   return mjv_check_launch("attention");
 }
 
 }  // namespace
 
 extern "C" int mjv_attention_set_variant(int32_t v) {
-  if (v < 0 || v > 3) {   // 0 = production; 1-3 = the timing experiments documented at attn_kernel
+  if (v < 0 || v > 4) {   // 0 = production; 1-3 = the timing experiments documented at attn_kernel; 4 = the register-staged kernel of round 1 (A/B)
     mjv_set_error("attention_set_variant: %d not in {0..3}", v);
     return MJV_E_ARG;
   }
