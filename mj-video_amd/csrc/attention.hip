@@ -454,10 +454,18 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
       }
     };
     if (solo) {
-      for (int kt = 0; kt < n_tiles; ++kt) {
-        issue(kt, 0, 0, 4);
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): one wave, its own LDS operations are in order
+      // one wave: no barriers (its own LDS operations are in order), the next tile's DMA - all four shares - in flight
+      // under the current tile's math
+      issue(0, 0, 0, 4);
+      for (int kt = 0; kt < n_tiles; kt += 2) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        if (kt + 1 < n_tiles) issue(kt + 1, TB, 0, 4);
         tile_math(kt, false, Buf0{});
+        if (kt + 1 < n_tiles) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          if (kt + 2 < n_tiles) issue(kt + 2, 0, 0, 4);
+          tile_math(kt + 1, false, Buf1{});
+        }
       }
     } else {
       issue(0, 0, wave, wave + 1);
