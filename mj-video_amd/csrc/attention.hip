@@ -525,7 +525,10 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 // control flow, heaviest-first causal order, the one-wave ragged block.  Round 2: two K/V buffers in LDS with ONE barrier per
 // key tile instead of two (the lever that gave the GEMM main loop +2-7 %) is bit-identical and measures 0 % at D = 128
 // (same occupancy) and -4 % at D = 64 (three workgroups per CU instead of four): with several workgroups per CU the barrier
-// waits are already covered by the other workgroups' waves.
+// waits are already covered by the other workgroups' waves.  (With LDS-DMA staging instead of register staging the two-buffer
+// form does pay: see DMA below.)  A half-tile path for tiles whose second 32 keys are all masked (the 17th tile of the vision
+// tower's 1025 keys; the diagonal tile of every other wave under the causal mask) is bit-identical and measured -1 % at
+// D = 64 and -3 % at D = 128: the second copy of the tile code costs registers (2 spills / +40) and instruction cache.
 
 int g_attn_variant = 0;
 
