@@ -29,7 +29,7 @@ def run(name, n_seq, L, H, G, D, causal, mode):
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 variants = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 for rnd in range(rounds):
-    for v in variants:
+    for v in variants[rnd % len(variants):] + variants[:rnd % len(variants)]:   # rotated: the first variant of a round is favoured
         ops.attention_set_variant(v)
         print("variant", v, end="  ")
         run("vit_d64", 64, 1025, 16, 1, 64, False, 0)

@@ -75,8 +75,10 @@ ROUNDS = int(os.environ.get("MJV_BENCH_ROUNDS", 3))
 for name, M, N, K, epi in shapes:
     line = f"{name:16s} M={M:6d} N={N:6d} K={K:5d}"
     best = {t: (1e9, 0) for t in tiles}
-    for _ in range(ROUNDS):          # interleaved rounds in one process (variants A/B on the same device and clock)
-        for t in tiles:
+    for rnd in range(ROUNDS):        # interleaved rounds in one process (variants A/B on the same device and clock)
+        # rotated order: the first variant timed after the host-side pause of a new round runs 1-3 % faster on some shapes
+        # (boost clocks), which a fixed order would always hand to the same variant
+        for t in tiles[rnd % len(tiles):] + tiles[:rnd % len(tiles)]:
             ms, tf = bench(M, N, K, epi, t, iters=10)
             if ms < best[t][0]:
                 best[t] = (ms, tf)
