@@ -466,6 +466,40 @@ def test_gemm_split_k_on_256_tiles(cuda, M, N, K, epi):
     assert torch.equal(outs[0], ref)
 
 
+def test_attention_dma_staging_race_screen(cuda):
+    """the attention kernel stages K / V by LDS-DMA into two buffers with one barrier per key tile (round 2); the register-staged
+    kernel of round 1 (variant 4) computes the same arithmetic in the same order: on the model's shapes, a ragged shape and a
+    GQA causal shape the two must agree bit for bit, and repeated launches on a chip kept busy by a GEMM on another stream must
+    reproduce the first one (a missing wait or barrier shows up as a changing result)"""
+    from mj_video_amd import ops
+    g = torch.Generator().manual_seed(23)
+    side = torch.cuda.Stream()
+    big_a = torch.randn(8192, 2048, device=cuda).to(BF)
+    big_w = torch.randn(4096, 2048, device=cuda).to(BF)
+    big_o = torch.empty(8192, 4096, dtype=BF, device=cuda)
+    for (n_seq, L, H, G, D, causal, mode) in [(16, 1025, 16, 1, 64, False, 0), (4, 2186, 16, 2, 128, True, 1), (3, 130, 16, 1, 64, False, 0),
+                                              (2, 4096, 8, 2, 128, True, 1), (5, 33, 4, 1, 64, True, 0)]:
+        N = n_seq * L
+        q = torch.randn(N, H * D, generator=g).to(BF).to(cuda)
+        k = torch.randn(N, (H // G) * D, generator=g).to(BF).to(cuda)
+        v = torch.randn(N, (H // G) * D, generator=g).to(BF).to(cuda)
+        cu = torch.arange(0, (n_seq + 1) * L, L, dtype=torch.int32, device=cuda)
+        outs = []
+        try:
+            for var in (4, 0, 0, 0, 0, 0):
+                ops.attention_set_variant(var)
+                with torch.cuda.stream(side):
+                    ops.gemm(big_a, big_w, big_o, ops.EPI_BIAS)
+                o = torch.zeros(N, H * D, dtype=BF, device=cuda)
+                ops.attention(q, k, v, o, cu, L, H, G, D, causal, D ** -0.5, mode)
+                outs.append(o)
+        finally:
+            ops.attention_set_variant(0)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs[1:]):
+            assert torch.equal(o, outs[0]), f"D={D} L={L} causal={causal}: launch {i + 1} differs from the register-staged kernel"
+
+
 def test_gemm_skinny_pipeline_race_screen(cuda):
     """the 64 x 32 kernel keeps two K-tiles of LDS-DMA in flight across its one barrier per K-tile (counted vmcnt, three
     buffers): repeat exact-integer problems of the shapes it serves (tails of 64 / 80 rows, deep and shallow K, the gating
