@@ -256,9 +256,10 @@ def test_patchify_cls_embed(cuda):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.fixture(params=[0])
+@pytest.fixture(params=[0, 4])
 def attn_variant(request, cuda):
-    """attention schedule selector (one schedule is built in at present; the hook stays for A/B experiments)"""
+    """attention staging selector: 0 = automatic (LDS-DMA staging up to 4096 keys, register staging beyond), 4 = the
+    register-staged kernel at every length (on the two production shapes; other shapes ignore the selector)"""
     from mj_video_amd import ops
     ops.attention_set_variant(request.param)
     yield request.param
