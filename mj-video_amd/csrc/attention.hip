@@ -14,6 +14,8 @@
 #include "mjv_common.h"
 #include <math.h>
 #include <type_traits>
+#include <utility>
+#include <algorithm>
 
 namespace {
 
@@ -530,6 +532,502 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 // tower's 1025 keys; the diagonal tile of every other wave under the causal mask) is bit-identical and measured -1 % at
 // D = 64 and -3 % at D = 128: the second copy of the tile code costs registers (2 spills / +40) and instruction cache.
 
+
+// =====================================================================================================================
+// attn2_kernel (round 3): 64 queries per wave as two 32-query sub-blocks A / B, and an IN-WAVE software pipeline.
+//
+// Counters on the round-2 kernel (profiles/r02_a_attn_pmc_counters.txt) say what it loses: every wave runs {8 QK^T MFMAs |
+// ~150 vector instructions of softmax | 8 PV MFMAs} strictly in turn, the matrix pipe is busy 29 % of the time and a vector
+// instruction co-executes in only 22 % of those cycles.  The calibration streams of tools/micro/issue_model say how to get
+// the overlap: NOT from other waves (phased streams of 2-4 waves per SIMD overlap 0.4-0.6) but from INDEPENDENT vector work
+// that follows each MFMA in the SAME wave's stream (0.72 at any occupancy).  One wave therefore owns two query sub-blocks and
+// walks a key tile as four units u = (A,h0) (B,h0) (A,h1) (B,h1) (h = 32-key half of the 64-key tile), software-pipelined:
+//
+//     slot s :  MFMAs  PV(s-2), QK(s)     ||     vector work  softmax(s-1)            s = 0 .. 5
+//
+// so every MFMA is followed by a slice of the softmax of the PREVIOUS unit (independent registers).  The slices are pinned
+// between the MFMAs with sched_barrier (left alone the compiler issues all MFMAs first).
+//
+// The softmax is "optimistic": the running offset M of a query is an INTEGER in exp2 units (M = ceil of the rounded score in
+// log2 units at the time it was last set) and a unit does NOT compute its row max: p = exp2(s c - M) directly, and only if a
+// lane's partial row sum comes out above 2^20 (or NaN: the first tile starts from M = -inf) the unit is redone with
+// M <- max(M, ceil(unit max)).  Because M is an integer every rescale factor is an exact power of two, and bf16 rounding of P
+// commutes with it: O / l do not depend on WHEN a query's offset was raised (no rounding-level difference between the lazy and
+// the eager schedule), only on the offsets being integers.  This removes the max (16 v_max3 + exchange per unit), the exp of
+// the rescale factor and, almost always, the rescale of the O accumulators from the per-tile vector work: 4.7 -> 3.7 vector
+// instructions per score at D = 64.  Row sums stay lane-partial until the epilogue (one cross-half exchange per query block
+// instead of one per tile).
+//
+// Sequences whose length is 1 (mod 64) - the vision tower's 1 + 32^2 tokens - would need a 17th key tile and a 9th query block
+// for ONE token.  For them (non-causal only) key 0 becomes the INITIAL STATE of the online softmax (M = ceil(s(q, k_0) c),
+// l = p_0, O = bf16(p_0) v_0: 32 FMAs per lane, once) and the key tiles start at key 1; the query blocks start at query 1 and
+// query 0 is run by one wave of an extra block.
+// =====================================================================================================================
+namespace v2 {
+
+template <class Fn, int... I>
+MJV_DEV void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class Fn>
+MJV_DEV void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr float BIGSUM = 1048576.f;   // 2^20: a lane's partial row sum above this redoes the unit with a raised offset
+
+struct Pos { int slot, kind, unit, f; };   // kind 0 = QK^T, 1 = PV
+// MFMA stream of one key tile: slot s holds the F MFMAs of PV(s - 2) (if that unit exists), then the F of QK(s)
+template <int F, int U>
+constexpr Pos stream_pos(int i) {
+  int s = 0;
+  while (true) {
+    const int npv = (s >= 2 && s - 2 < U) ? F : 0;
+    const int nqk = (s < U) ? F : 0;
+    if (i < npv) return Pos{s, 1, s - 2, i};
+    i -= npv;
+    if (i < nqk) return Pos{s, 0, s, i};
+    i -= nqk;
+    ++s;
+  }
+}
+template <int F, int U>
+constexpr int slot_first(int s) {   // stream index of the first MFMA of slot s
+  int i = 0;
+  for (int t = 0; t < s; ++t) i += ((t >= 2 && t - 2 < U) ? F : 0) + ((t < U) ? F : 0);
+  return i;
+}
+template <int F, int U>
+constexpr int slot_size(int s) { return ((s >= 2 && s - 2 < U) ? F : 0) + ((s < U) ? F : 0); }
+
+// Diagnostic build only (-DMJV_ATTN_STAMPS, tools/attn_stamps.py): s_memtime stamps at the segment boundaries of the tile
+// loop, summed per wave in scalar registers and written to a buffer of their own after the loop; never in the product build.
+#ifdef MJV_ATTN_STAMPS
+__device__ unsigned long long* g_stamp_out = nullptr;
+#define MJV_STAMP(i)                                                                       \
+  do {                                                                                     \
+    unsigned long long t_;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    st_acc[i] += t_ - st_prev;                                                             \
+    st_prev = t_;                                                                          \
+  } while (0)
+#else
+#define MJV_STAMP(i) do { } while (0)
+#endif
+
+template <int D, bool CAUSAL, int RM, int NW, bool SOLO = false>
+__global__ __launch_bounds__(64 * NW, (D == 64) ? 2 : 1) void attn2_kernel(AttnArgs p) {
+  constexpr int PK = D * 2, PV = D * 2;           // unpadded rows, swizzled chunks (as the DMA form of attn_kernel)
+  constexpr int KBYTES = KB * PK, VBYTES = KB * PV, TB = KBYTES + VBYTES;
+  constexpr int QBW = 64 * NW;                    // queries per workgroup
+  constexpr int F = D / 16;                       // MFMAs per unit and product
+  static_assert((TB & (TB - 1)) == 0, "the buffer toggle XORs TB into the fragment offsets");
+  __shared__ __attribute__((aligned(16))) char smem[2 * TB];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const BlockId bid = decode_block(p);
+  if (!bid.valid) return;
+  const int seq = bid.seq, head = bid.head;
+  const int s0 = p.cu[seq];
+  const int len = p.cu[seq + 1] - s0;
+  const int kvh = head / p.kv_group;
+  // first-key-as-initial-state ("peel"): workgroup-uniform
+  const bool peel = !CAUSAL && len > 1 && ((len - 1) % KB == 0);
+  const int klen = peel ? len - 1 : len;          // keys that go through the tiles (rows s0 + peel ...)
+  const int nq_main = peel ? len - 1 : len;       // queries of the ordinary blocks (queries peel ...)
+  const int nb_main = (nq_main + QBW - 1) / QBW;
+  const int qb = CAUSAL ? nb_main - 1 - bid.qb : bid.qb;   // causal: heaviest blocks first
+  if (CAUSAL ? (qb < 0) : (qb > nb_main || (qb == nb_main && !peel))) return;
+  const bool cls_block = peel && qb == nb_main;   // the block of query 0
+  // SOLO: that block is run by wave 0 ALONE (the others leave; one wave's LDS operations are in order, so its loop has no
+  // barrier and it issues every share of the DMA); otherwise all waves stay and share the staging
+  const bool solo = SOLO && cls_block;
+  if (solo && wave > 0) return;
+
+  // this wave's queries: sub-block A = qw0 + l31, B = qw0 + 32 + l31 (sequence-relative indices)
+  const int qw0 = cls_block ? 0 : (peel ? 1 : 0) + qb * QBW + wave * 64;
+  const int nq_wave = cls_block ? (wave == 0 ? 1 : 0) : max(0, min(64, len - qw0));   // valid queries of this wave
+  const bool hasA = nq_wave > 0, hasB = nq_wave > 32;
+  int qi[2];
+  qi[0] = cls_block ? 0 : qw0 + l31;
+  qi[1] = qw0 + 32 + l31;
+
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float c_exp = (RM == RM_POW2) ? p.scale * LOG2E : LOG2E;   // exp2 argument = (rounded score) * c_exp - M
+
+  // Q fragments (B operand): lane holds Q[query l31][d = 16 ks + 8 hi + j]
+  bf16x8 qf[2][F];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const int qr = s0 + (qi[sb] < len ? qi[sb] : len - 1);
+    const u16* qp = p.Q + (long)qr * p.ldq + (long)head * p.qhs + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < F; ++ks) qf[sb][ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  f32x16 oacc[2][D / 32];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[sb][i][r] = 0.f;
+  float Mq[2] = {-INFINITY, -INFINITY};   // integer offset in exp2 units (same value in the two half-lanes of a query)
+  float lsum[2] = {0.f, 0.f};             // LANE-PARTIAL row sums (this lane's keys only); halves are added in the epilogue
+#ifdef MJV_ATTN_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+#endif
+
+  const u16* Kg = p.K + (long)kvh * p.khs;
+  const u16* Vg = p.V + (long)kvh * p.vhs;
+  const char* const k_seq = (const char*)(Kg + (long)(s0 + (peel ? 1 : 0)) * p.ldk);   // key row 0 of the tiles
+  const char* const v_seq = (const char*)(Vg + (long)(s0 + (peel ? 1 : 0)) * p.ldv);
+
+  if (peel && hasA) {
+    // key 0 as the initial state.  s = q . k_0 in fp32 (this lane's 8-element groups, then the other half-lane's), rounded
+    // like every score; M = ceil(s c); p_0 = exp2(s c - M) in (1/2, 1]; l = p_0 (counted in the hi = 0 lane only: row sums
+    // are lane-partial); O = bf16(p_0) * v_0 - what the MFMA would have accumulated for this key.
+    const u16* k0p = Kg + (long)s0 * p.ldk + 8 * hi;
+    const u16* v0p = Vg + (long)s0 * p.ldv;
+    u32x4 kraw[F];
+#pragma unroll
+    for (int ks = 0; ks < F; ++ks) kraw[ks] = *(const u32x4*)(k0p + ks * 16);
+    u32x2 vraw[D / 32][4];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) vraw[dt][g] = *(const u32x2*)(v0p + dt * 32 + 8 * g + 4 * hi);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      float dot = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < F; ++ks) {
+        float kf[8], qv[8];
+        unpack8(kraw[ks], kf);
+        unpack8(__builtin_bit_cast(u32x4, qf[sb][ks]), qv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dot = fmaf(qv[j], kf[j], dot);
+      }
+      dot = xhalf_sum(dot);
+      const float arg = round_score<RM>(dot, p.scale) * c_exp;
+      const float m0 = ceilf(arg);
+      const float p0 = __builtin_amdgcn_exp2f(arg - m0);
+      const float pb = rbf(p0);
+      Mq[sb] = m0;
+      lsum[sb] = hi == 0 ? p0 : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          oacc[sb][dt][4 * g + 0] = pb * __uint_as_float(vraw[dt][g][0] << 16);
+          oacc[sb][dt][4 * g + 1] = pb * __uint_as_float(vraw[dt][g][0] & 0xffff0000u);
+          oacc[sb][dt][4 * g + 2] = pb * __uint_as_float(vraw[dt][g][1] << 16);
+          oacc[sb][dt][4 * g + 3] = pb * __uint_as_float(vraw[dt][g][1] & 0xffff0000u);
+        }
+    }
+  }
+
+  const int q_last_w = qw0 + nq_wave - 1;                        // last valid query of this wave
+  const int kv_end = CAUSAL ? min(klen, qb * QBW + QBW) : klen;  // keys this workgroup needs
+  const int n_tiles = (kv_end + KB - 1) / KB;
+
+  // ---- LDS-DMA staging (same image and swizzles as attn_kernel<.., DMA = true>), NW waves share a tile's 2 x CH instructions
+  constexpr int CH = D / 8, NI = CH / NW;
+  static_assert(CH % NW == 0, "DMA instructions per operand must divide over the waves");
+  unsigned kso[NI], vso[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int slot = (j * NW + wave) * 64 + lane;
+    const int row = slot / CH, cl = slot % CH;
+    const int sk = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    const int sv = (D == 64) ? (((row >> 1) & 1) * 4) : ((row & 3) * 4);
+    kso[j] = (unsigned)(row * (int)p.ldk + ((cl ^ sk) * 8)) * 2u;
+    vso[j] = (unsigned)(row * (int)p.ldv + ((cl ^ sv) * 8)) * 2u;
+  }
+  // LDS-DMA as inline assembly: issued through the builtin, the compiler's wait-count pass treats the transposed LDS reads of
+  // the V fragments as possibly aliasing the DMA in flight and puts an s_waitcnt vmcnt(0) in front of the first of them - the
+  // whole flight time of the NEXT tile's DMA (issued a few hundred cycles earlier) exposed once per tile.  The DMA of tile
+  // kt + 1 targets the buffer nobody reads during tile kt; its completion is waited for (asm, vmcnt(0)) at the top of the
+  // next iteration, before the barrier.  M0 (LDS destination, wave-uniform) is written in the statement that uses it.
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+  auto dma16 = [&](const char* base, unsigned voff, unsigned lds_dst) __attribute__((always_inline)) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst)
+                 : "memory");
+  };
+  auto issue = [&](int kt, int boff) __attribute__((always_inline)) {
+    const bool whole = kt * KB + KB <= klen;
+    for (int w = solo ? 0 : wave; w < (solo ? NW : wave + 1); ++w) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        unsigned ko, vo;
+        if (whole && w == wave) {
+          ko = kso[j] + (unsigned)(kt * KB) * (unsigned)p.ldk * 2u;
+          vo = vso[j] + (unsigned)(kt * KB) * (unsigned)p.ldv * 2u;
+        } else {
+          const int slot = (j * NW + w) * 64 + lane;
+          const int row = slot / CH, cl = slot % CH;
+          const int sk = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+          const int sv = (D == 64) ? (((row >> 1) & 1) * 4) : ((row & 3) * 4);
+          int gr = kt * KB + row;
+          gr = gr < klen ? gr : klen - 1;                   // rows past the end: any valid row (masked later)
+          ko = (unsigned)(gr * (int)p.ldk + ((cl ^ sk) * 8)) * 2u;
+          vo = (unsigned)(gr * (int)p.ldv + ((cl ^ sv) * 8)) * 2u;
+        }
+        dma16(k_seq, ko, lds0 + (unsigned)(boff + (j * NW + w) * 1024));
+        dma16(v_seq, vo, lds0 + (unsigned)(boff + KBYTES + (j * NW + w) * 1024));
+      }
+    }
+  };
+
+  // per-lane LDS byte offsets of the fragments (the swizzle terms are lane constants)
+  int koff[F], vboff[D / 32];
+  {
+    const int ksw = (D == 64) ? ((l31 >> 1) & 7) : (l31 & 15);
+#pragma unroll
+    for (int ks = 0; ks < F; ++ks) koff[ks] = l31 * PK + (((hi + 2 * ks) ^ ksw) << 4);
+    const int li = lane & 15, g16 = (lane >> 4) & 1, trow = li >> 2, tcol = 4 * (li & 3);
+    const int svl = (D == 64) ? (((trow >> 1) & 1) * 4) : (trow * 4);
+#pragma unroll
+    for (int g = 0; g < D / 32; ++g)
+      vboff[g] = (4 * hi + trow) * PV + (((g * 4 + g16 * 2 + (tcol >> 3)) ^ svl) << 4) + (tcol & 7) * 2;
+  }
+
+  const f32x2 c2 = {c_exp, c_exp};
+  const f32x2 scale2 = {p.scale, p.scale};
+
+  // one pair of scores of a unit -> two exponentials (in place of nothing: the scores stay live for a possible redo)
+  auto do_pair = [&](const f32x16& S, int r, float nmb, f32x2& psum, unsigned& pw) __attribute__((always_inline)) {
+    const f32x2 a2 = {S[r], S[r + 1]};
+    f32x2 sr;
+    if constexpr (RM == RM_MUL) sr = round_pair(a2 * scale2);
+    else {
+      sr = round_pair(a2);
+      if constexpr (RM == RM_DIV) sr = round_pair(sr * scale2);
+    }
+    const f32x2 e2 = sr * c2 + f32x2{nmb, nmb};
+    const f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+    psum += pv;
+    pw = pack_pair(pv);
+  };
+  // rare path: raise the offset of sub-block sb to cover unit scores S, rescale its state, recompute the unit's P
+  auto redo = [&](const f32x16& S, auto sbc, f32x2& psum, unsigned (&pw)[8]) __attribute__((always_inline)) {
+    constexpr int sb = decltype(sbc)::value;
+    float mx = S[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+    mx = xhalf_max(mx);
+    const float arg = round_score<RM>(mx, p.scale) * c_exp;
+    float mn = fmaxf(Mq[sb], ceilf(arg));
+    if (!(mn > -INFINITY)) mn = 0.f;                       // nothing but masked keys so far
+    const float alpha = __builtin_amdgcn_exp2f(Mq[sb] - mn);   // exact power of two (0 from the initial -inf)
+    lsum[sb] *= alpha;
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[sb][i][r] *= alpha;
+    Mq[sb] = mn;
+    psum = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) do_pair(S, r, -mn, psum, pw[r >> 1]);
+  };
+
+  const char* const Ksb = smem;
+  const char* const Vsb = smem + KBYTES;
+  auto read_k = [&](int h, int ks, bf16x8& f) __attribute__((always_inline)) { f = *(const bf16x8*)(Ksb + h * 32 * PK + koff[ks]); };
+  auto read_v = [&](int h, int f_, bf16x8& f) __attribute__((always_inline)) {         // f_ = 2 dt + s2  ->  keys 32 h + 16 s2 .., d tile dt
+    const char* vp = Vsb + vboff[f_ >> 1] + (2 * h + (f_ & 1)) * 16 * PV;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * PV));
+    const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    f = __builtin_bit_cast(bf16x8, v8);
+  };
+  auto pfrag = [&](const unsigned (&pw)[8], int s2) __attribute__((always_inline)) {
+    return __builtin_bit_cast(bf16x8, u32x4{pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]});
+  };
+
+    // ---- software pipeline over the units of a whole, unmasked tile: U = 4 (unit u: sub-block u & 1, key half u >> 1) for a
+    // wave with both sub-blocks, U = 2 (sub-block A, key half u) for a wave with at most 32 queries (the block of query 0)
+  auto pipeline = [&](auto uc_) __attribute__((always_inline)) {
+      constexpr int U = decltype(uc_)::value;
+      f32x16 S[U];
+      unsigned Pw[U][8];
+      f32x2 psum[U];
+      constexpr int NS = 2 * U * F, AHEAD = 3, RING = 4;
+      bf16x8 ring[RING];
+      auto rd = [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr Pos q = stream_pos<F, U>(i);
+        constexpr int h = (U == 4) ? (q.unit >> 1) : q.unit;
+        if constexpr (q.kind == 0) read_k(h, q.f, ring[i % RING]);
+        else read_v(h, q.f, ring[i % RING]);
+      };
+      static_for<AHEAD>([&](auto ic) __attribute__((always_inline)) { rd(ic); });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NS>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr Pos q = stream_pos<F, U>(i);
+        if constexpr (i + AHEAD < NS) rd(std::integral_constant<int, i + AHEAD>{});
+        constexpr int sb = (U == 4) ? (q.unit & 1) : 0;
+        if constexpr (q.kind == 0) {
+          if constexpr (q.f == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[q.unit][r] = 0.f;
+          }
+          S[q.unit] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i % RING], qf[sb][q.f], S[q.unit], 0, 0, 0);
+        } else {
+          oacc[sb][q.f >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i % RING], pfrag(Pw[q.unit], q.f & 1),
+                                                                     oacc[sb][q.f >> 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the slice of softmax(slot - 1) that goes behind this MFMA
+        constexpr int s = q.slot;
+        if constexpr (s >= 1 && s <= U) {
+          constexpr int us = s - 1;                                     // unit whose softmax runs in this slot
+          constexpr int j = i - slot_first<F, U>(s), cnt = slot_size<F, U>(s);
+          constexpr int pr0 = j * 8 / cnt, pr1 = (j + 1) * 8 / cnt;     // pairs [pr0, pr1) of the unit's 8
+          if constexpr (j == 0) psum[us] = f32x2{0.f, 0.f};
+          constexpr int sbs = (U == 4) ? (us & 1) : 0;
+          const float nmb = -Mq[sbs];
+#pragma unroll
+          for (int pr = pr0; pr < pr1; ++pr) do_pair(S[us], 2 * pr, nmb, psum[us], Pw[us][pr]);
+          if constexpr (j == cnt - 1) {
+            float tot = psum[us][0] + psum[us][1];
+            if (__any(!(tot < BIGSUM))) {
+              redo(S[us], std::integral_constant<int, sbs>{}, psum[us], Pw[us]);
+              tot = psum[us][0] + psum[us][1];
+            }
+            lsum[sbs] += tot;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef MJV_ATTN_STAMPS
+        if constexpr (i + 1 == slot_first<F, U>(q.slot) + slot_size<F, U>(q.slot)) MJV_STAMP(4 + q.slot);
+#endif
+      });
+      };
+  // ---- general path (ragged blocks, tiles on the diagonal or across the sequence end): unit after unit, with masks
+  auto general = [&](int kt) __attribute__((always_inline)) {
+    const int k0 = kt * KB;
+    if (!hasA || (CAUSAL && k0 > q_last_w)) return;       // no query here / tile above this wave's diagonal: staging help only
+    static_for<4>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int sb = u & 1, h = u >> 1;
+      const int kb = k0 + 32 * h;
+      const int q_last = qw0 + 32 * sb + min(31, nq_wave - 32 * sb - 1);   // last valid query of the sub-block
+      if ((sb == 1 && !hasB) || kb >= klen || (CAUSAL && kb > q_last)) return;   // wave-uniform
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < F; ++ks) {
+        bf16x8 kf;
+        read_k(h, ks, kf);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sb][ks], S, 0, 0, 0);
+      }
+      const int qmin = qw0 + 32 * sb;
+      if (kb + 32 > klen || (CAUSAL && kb + 31 > qmin)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= klen || (CAUSAL && key > qi[sb])) S[r] = -INFINITY;
+        }
+      }
+      unsigned pw[8];
+      f32x2 ps = {0.f, 0.f};
+      const float nmb = -Mq[sb];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) do_pair(S, r, nmb, ps, pw[r >> 1]);
+      float tot = ps[0] + ps[1];
+      if (__any(!(tot < BIGSUM))) {
+        redo(S, std::integral_constant<int, sb>{}, ps, pw);
+        tot = ps[0] + ps[1];
+      }
+      lsum[sb] += tot;
+#pragma unroll
+      for (int f_ = 0; f_ < F; ++f_) {
+        bf16x8 vf;
+        read_v(h, f_, vf);
+        oacc[sb][f_ >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfrag(pw, f_ & 1), oacc[sb][f_ >> 1], 0, 0, 0);
+      }
+    });
+  };
+
+  // every load the compiler counts (Q fragments, key / value row 0) is retired HERE, in a form its wait-count pass reads: the
+  // loop's DMA is inline assembly, which that pass does not see, and a compiler-counted load still pending at the loop
+  // header would get counted waits inside the loop (vmcnt(7) ... vmcnt(0) in front of the first MFMAs that read the Q
+  // fragments) that in reality wait for the youngest operations in the queue - the DMA just issued
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef MJV_ATTN_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+  const unsigned long long st_begin = st_prev;
+#endif
+  issue(0, 0);
+  // One iteration of the tile loop; the loop is written three times, each with ONE kind of tile arithmetic in its body: a body
+  // that chooses between the pipelines and the general path per tile makes the register allocator give the O accumulators a
+  // different home on every path (64 v_mov per tile between them, and spills in the pipeline).  Whole, unmasked tiles come
+  // first in every wave's key order (the ragged last tile and the causal diagonal are at the end), so the split is by position.
+  auto step = [&](int kt, auto&& math) __attribute__((always_inline)) {
+    // tile kt sits in buffer kt & 1: every wave's share has landed after the wait + barrier, and every wave is done with
+    // tile kt - 1 (the other buffer), which the next DMA overwrites
+    MJV_STAMP(0);                      // loop overhead (address toggles, branch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MJV_STAMP(1);                      // own DMA of this tile landed
+    if (!solo) __syncthreads();
+    MJV_STAMP(2);                      // barrier
+    if (kt + 1 < n_tiles) issue(kt + 1, ((kt + 1) & 1) * TB);
+    MJV_STAMP(3);                      // DMA issue
+    math(kt);
+    MJV_STAMP(11);                     // (general-path tiles; the pipelines stamp their slots 4 .. 9 themselves)
+    // the fragment addresses follow the tile to the other buffer (TB is a power of two above every offset in a buffer)
+#pragma unroll
+    for (int ks = 0; ks < F; ++ks) koff[ks] ^= TB;
+#pragma unroll
+    for (int g = 0; g < D / 32; ++g) vboff[g] ^= TB;
+  };
+  // leading tiles that are whole (all 64 keys exist) and need no mask for any query of this wave
+  const int n_whole = !hasA ? 0 : min(n_tiles, CAUSAL ? max(0, (qw0 + 1) / KB) : klen / KB);
+  int kt = 0;
+  if (hasB) {
+    for (; kt < n_whole; ++kt) step(kt, [&](int) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 4>{}); });
+  } else if (hasA) {
+    for (; kt < n_whole; ++kt) step(kt, [&](int) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 2>{}); });
+  }
+  for (; kt < n_tiles; ++kt) step(kt, general);
+
+#ifdef MJV_ATTN_STAMPS
+  if (g_stamp_out && lane == 0) {
+    unsigned long long* d = g_stamp_out + ((long)blockIdx.x * NW + wave) * 16;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) d[i] = st_acc[i];
+    d[12] = (unsigned long long)n_tiles;
+    d[13] = st_prev - st_begin;
+    d[14] = (unsigned long long)((hasA ? 1 : 0) + (hasB ? 1 : 0) + (cls_block ? 4 : 0));
+  }
+#endif
+  // ---- epilogue: O[query][d] = O^T / l ; lane = query, register r <-> d = 32 dt + (r & 3) + 8 (r >> 2) + 4 hi
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const float l = xhalf_sum(lsum[sb]);
+    const bool ok = cls_block ? (sb == 0 && l31 == 0) : (qi[sb] < len);
+    if (!ok) continue;
+    const float inv = 1.0f / l;
+    u16* op = p.O + (long)(s0 + qi[sb]) * p.ldo + (long)head * p.ohs;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 v = {pack2bf(oacc[sb][dt][4 * g] * inv, oacc[sb][dt][4 * g + 1] * inv),
+                   pack2bf(oacc[sb][dt][4 * g + 2] * inv, oacc[sb][dt][4 * g + 3] * inv)};
+        *(u32x2*)(op + dt * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+}  // namespace v2
+
 int g_attn_variant = 0;
 
 template <int D, bool CAUSAL>
@@ -545,11 +1043,30 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
     if (g_attn_variant == 1) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 1>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
     if (g_attn_variant == 2) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 2>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
     if (g_attn_variant == 3) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 3>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
-    if (g_attn_variant == 4) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 0, false>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
+  }
+  // round 3: the two-sub-block pipelined kernel (attn2_kernel) for sequences of up to 4096 keys; variant 5 = the round-2 choice
+  const bool dma = max_seqlen <= 4096 && g_attn_variant != 4;   // variant 4: the register-staged kernel for EVERY shape
+  if constexpr (D == 64 && !CAUSAL) if (dma && g_attn_variant != 5) {
+    auto go = [&](auto nwc, auto soloc) {
+      constexpr int NW = decltype(nwc)::value;
+      constexpr bool SOLO = decltype(soloc)::value;
+      // non-causal launches may peel key / query 0 of a sequence (length = 1 mod 64): one more block for query 0
+      const int nqb2 = CAUSAL ? (max_seqlen + 64 * NW - 1) / (64 * NW)
+                              : std::max((max_seqlen + 64 * NW - 1) / (64 * NW), (max_seqlen - 1 + 64 * NW - 1) / (64 * NW) + 1);
+      a.n_qb = nqb2;
+      const int total2 = nqb2 * a.n_heads * n_seqs;
+      const dim3 grid2(8 * ((total2 + 7) / 8));
+      if (a.round_mode == 1) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_DIV, NW, SOLO>), grid2, dim3(64 * NW), 0, s, a);
+      else if (pow2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_POW2, NW, SOLO>), grid2, dim3(64 * NW), 0, s, a);
+      else hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_MUL, NW, SOLO>), grid2, dim3(64 * NW), 0, s, a);
+    };
+    if (g_attn_variant == 6) go(std::integral_constant<int, 2>{}, std::false_type{});
+    else if (g_attn_variant == 7) go(std::integral_constant<int, 4>{}, std::true_type{});
+    else go(std::integral_constant<int, 4>{}, std::false_type{});
+    return mjv_check_launch("attention");
   }
   // LDS-DMA staging up to 4096 keys per sequence (measured +2 ... +3 % at 1025 / 2186, 0 at 2048 non-causal); beyond that
   // the register-staged form is the faster one (causal, 8192 keys: 0.64 vs 0.66 ms), so the long-context config keeps it
-  const bool dma = max_seqlen <= 4096;
   if (a.round_mode == 1) {
     if (dma) hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV, 0, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_DIV, 0, false>), grid, dim3(256), 0, s, a);
@@ -565,9 +1082,16 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
 
 }  // namespace
 
+#ifdef MJV_ATTN_STAMPS
+extern "C" int mjv_attention_stamp_buffer(void* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  return hipMemcpyToSymbol(HIP_SYMBOL(v2::g_stamp_out), &q, sizeof(q)) == hipSuccess ? MJV_OK : MJV_E_LAUNCH;
+}
+#endif
+
 extern "C" int mjv_attention_set_variant(int32_t v) {
-  if (v < 0 || v > 4) {   // 0 = production; 1-3 = the timing experiments documented at attn_kernel; 4 = the register-staged kernel of round 1 (A/B)
-    mjv_set_error("attention_set_variant: %d not in {0..3}", v);
+  if (v < 0 || v > 7) {   // 0 = production; 1-3 = the timing experiments documented at attn_kernel; 4 = the register-staged kernel of round 1 (A/B)
+    mjv_set_error("attention_set_variant: %d not in {0..7}", v);
     return MJV_E_ARG;
   }
   g_attn_variant = v;

@@ -256,10 +256,10 @@ def test_patchify_cls_embed(cuda):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.fixture(params=[0, 4])
+@pytest.fixture(params=[0, 4, 5])
 def attn_variant(request, cuda):
-    """attention staging selector: 0 = automatic (LDS-DMA staging up to 4096 keys, register staging beyond), 4 = the
-    register-staged kernel at every length (on the two production shapes; other shapes ignore the selector)"""
+    """attention kernel selector: 0 = automatic (round 3: the two-sub-block pipelined kernel where instantiated), 4 = the
+    register-staged round-1 kernel for every shape, 5 = the round-2 choice (LDS-DMA staging up to 4096 keys)"""
     from mj_video_amd import ops
     ops.attention_set_variant(request.param)
     yield request.param
@@ -468,10 +468,12 @@ def test_gemm_split_k_on_256_tiles(cuda, M, N, K, epi):
 
 
 def test_attention_dma_staging_race_screen(cuda):
-    """the attention kernel stages K / V by LDS-DMA into two buffers with one barrier per key tile (round 2); the register-staged
-    kernel of round 1 (variant 4) computes the same arithmetic in the same order: on the model's shapes, a ragged shape and a
-    GQA causal shape the two must agree bit for bit, and repeated launches on a chip kept busy by a GEMM on another stream must
-    reproduce the first one (a missing wait or barrier shows up as a changing result)"""
+    """K / V tiles go to LDS by LDS-DMA into two buffers with one barrier per key tile.  Two screens on the model's shapes, a
+    ragged shape and GQA causal shapes, each on a chip kept busy by a GEMM on another stream (a missing wait or barrier shows
+    up as a changing result): (a) the round-2 kernel with LDS-DMA staging (variant 5) against its register-staged form
+    (variant 4), which computes the same arithmetic in the same order: bit for bit; (b) the automatic choice (round 3: the
+    two-sub-block pipelined kernel where it is instantiated, whose DMA is inline assembly behind hand-placed waits): repeated
+    launches must reproduce the first one bit for bit, and stay within the parity tolerance of the round-2 kernel."""
     from mj_video_amd import ops
     g = torch.Generator().manual_seed(23)
     side = torch.cuda.Stream()
@@ -479,26 +481,30 @@ def test_attention_dma_staging_race_screen(cuda):
     big_w = torch.randn(4096, 2048, device=cuda).to(BF)
     big_o = torch.empty(8192, 4096, dtype=BF, device=cuda)
     for (n_seq, L, H, G, D, causal, mode) in [(16, 1025, 16, 1, 64, False, 0), (4, 2186, 16, 2, 128, True, 1), (3, 130, 16, 1, 64, False, 0),
-                                              (2, 4096, 8, 2, 128, True, 1), (5, 33, 4, 1, 64, True, 0)]:
+                                              (2, 4096, 8, 2, 128, True, 1), (5, 33, 4, 1, 64, True, 0), (6, 257, 16, 1, 64, False, 0)]:
         N = n_seq * L
         q = torch.randn(N, H * D, generator=g).to(BF).to(cuda)
         k = torch.randn(N, (H // G) * D, generator=g).to(BF).to(cuda)
         v = torch.randn(N, (H // G) * D, generator=g).to(BF).to(cuda)
         cu = torch.arange(0, (n_seq + 1) * L, L, dtype=torch.int32, device=cuda)
-        outs = []
+        outs = {}
         try:
-            for var in (4, 0, 0, 0, 0, 0):
+            for var in (4, 5, 5, 5, 0, 0, 0, 0, 0, 0):
                 ops.attention_set_variant(var)
                 with torch.cuda.stream(side):
                     ops.gemm(big_a, big_w, big_o, ops.EPI_BIAS)
                 o = torch.zeros(N, H * D, dtype=BF, device=cuda)
                 ops.attention(q, k, v, o, cu, L, H, G, D, causal, D ** -0.5, mode)
-                outs.append(o)
+                outs.setdefault(var, []).append(o)
         finally:
             ops.attention_set_variant(0)
         torch.cuda.synchronize()
-        for i, o in enumerate(outs[1:]):
-            assert torch.equal(o, outs[0]), f"D={D} L={L} causal={causal}: launch {i + 1} differs from the register-staged kernel"
+        for i, o in enumerate(outs[5]):
+            assert torch.equal(o, outs[4][0]), f"D={D} L={L} causal={causal}: DMA launch {i} differs from the register-staged kernel"
+        for i, o in enumerate(outs[0][1:]):
+            assert torch.equal(o, outs[0][0]), f"D={D} L={L} causal={causal}: launch {i + 1} of the automatic kernel differs from launch 0"
+        rel = (outs[0][0].float() - outs[4][0].float()).norm() / outs[4][0].float().norm()
+        assert rel.item() < 4e-3, f"D={D} L={L}: automatic kernel vs round-2 kernel relative L2 {rel.item():.2e}"
 
 
 def test_gemm_skinny_pipeline_race_screen(cuda):
