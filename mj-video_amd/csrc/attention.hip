@@ -613,11 +613,14 @@ __device__ unsigned long long* g_stamp_out = nullptr;
 #define MJV_STAMP(i) do { } while (0)
 #endif
 
-template <int D, bool CAUSAL, int RM, int NW, bool SOLO = false>
-__global__ __launch_bounds__(64 * NW, (D == 64) ? 2 : 1) void attn2_kernel(AttnArgs p) {
+// NSUB = 32-query sub-blocks per wave: 2 at D = 64; 1 at D = 128, where two would need ~310 registers (the pipeline then
+// runs over the two key halves of the one sub-block: QK(h0) | QK(h1) || softmax(h0) | PV(h0) || softmax(h1) | PV(h1))
+template <int D, bool CAUSAL, int RM, int NW, bool SOLO = false, int NSUB = 2>
+__global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   constexpr int PK = D * 2, PV = D * 2;           // unpadded rows, swizzled chunks (as the DMA form of attn_kernel)
   constexpr int KBYTES = KB * PK, VBYTES = KB * PV, TB = KBYTES + VBYTES;
-  constexpr int QBW = 64 * NW;                    // queries per workgroup
+  constexpr int QW = 32 * NSUB;                   // queries per wave
+  constexpr int QBW = QW * NW;                    // queries per workgroup
   constexpr int F = D / 16;                       // MFMAs per unit and product
   static_assert((TB & (TB - 1)) == 0, "the buffer toggle XORs TB into the fragment offsets");
   __shared__ __attribute__((aligned(16))) char smem[2 * TB];
@@ -645,35 +648,37 @@ __global__ __launch_bounds__(64 * NW, (D == 64) ? 2 : 1) void attn2_kernel(AttnA
   if (solo && wave > 0) return;
 
   // this wave's queries: sub-block A = qw0 + l31, B = qw0 + 32 + l31 (sequence-relative indices)
-  const int qw0 = cls_block ? 0 : (peel ? 1 : 0) + qb * QBW + wave * 64;
-  const int nq_wave = cls_block ? (wave == 0 ? 1 : 0) : max(0, min(64, len - qw0));   // valid queries of this wave
-  const bool hasA = nq_wave > 0, hasB = nq_wave > 32;
-  int qi[2];
+  const int qw0 = cls_block ? 0 : (peel ? 1 : 0) + qb * QBW + wave * QW;
+  const int nq_wave = cls_block ? (wave == 0 ? 1 : 0) : max(0, min(QW, len - qw0));   // valid queries of this wave
+  const bool hasA = nq_wave > 0, hasB = NSUB == 2 && nq_wave > 32;
+  int qi[NSUB];
   qi[0] = cls_block ? 0 : qw0 + l31;
-  qi[1] = qw0 + 32 + l31;
+  if constexpr (NSUB == 2) qi[1] = qw0 + 32 + l31;
 
   constexpr float LOG2E = 1.4426950408889634f;
   const float c_exp = (RM == RM_POW2) ? p.scale * LOG2E : LOG2E;   // exp2 argument = (rounded score) * c_exp - M
 
   // Q fragments (B operand): lane holds Q[query l31][d = 16 ks + 8 hi + j]
-  bf16x8 qf[2][F];
+  bf16x8 qf[NSUB][F];
 #pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
+  for (int sb = 0; sb < NSUB; ++sb) {
     const int qr = s0 + (qi[sb] < len ? qi[sb] : len - 1);
     const u16* qp = p.Q + (long)qr * p.ldq + (long)head * p.qhs + 8 * hi;
 #pragma unroll
     for (int ks = 0; ks < F; ++ks) qf[sb][ks] = *(const bf16x8*)(qp + ks * 16);
   }
 
-  f32x16 oacc[2][D / 32];
+  f32x16 oacc[NSUB][D / 32];
 #pragma unroll
-  for (int sb = 0; sb < 2; ++sb)
+  for (int sb = 0; sb < NSUB; ++sb)
 #pragma unroll
     for (int i = 0; i < D / 32; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[sb][i][r] = 0.f;
-  float Mq[2] = {-INFINITY, -INFINITY};   // integer offset in exp2 units (same value in the two half-lanes of a query)
-  float lsum[2] = {0.f, 0.f};             // LANE-PARTIAL row sums (this lane's keys only); halves are added in the epilogue
+  float Mq[NSUB];   // integer offset in exp2 units (same value in the two half-lanes of a query)
+  float lsum[NSUB];                       // LANE-PARTIAL row sums (this lane's keys only); halves are added in the epilogue
+#pragma unroll
+  for (int sb = 0; sb < NSUB; ++sb) { Mq[sb] = -INFINITY; lsum[sb] = 0.f; }
 #ifdef MJV_ATTN_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
 #endif
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(64 * NW, (D == 64) ? 2 : 1) void attn2_kernel(AttnA
 #pragma unroll
       for (int g = 0; g < 4; ++g) vraw[dt][g] = *(const u32x2*)(v0p + dt * 32 + 8 * g + 4 * hi);
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
+    for (int sb = 0; sb < NSUB; ++sb) {
       float dot = 0.f;
 #pragma unroll
       for (int ks = 0; ks < F; ++ks) {
@@ -912,9 +917,9 @@ __global__ __launch_bounds__(64 * NW, (D == 64) ? 2 : 1) void attn2_kernel(AttnA
   auto general = [&](int kt) __attribute__((always_inline)) {
     const int k0 = kt * KB;
     if (!hasA || (CAUSAL && k0 > q_last_w)) return;       // no query here / tile above this wave's diagonal: staging help only
-    static_for<4>([&](auto uc) __attribute__((always_inline)) {
+    static_for<2 * NSUB>([&](auto uc) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value;
-      constexpr int sb = u & 1, h = u >> 1;
+      constexpr int sb = (NSUB == 2) ? (u & 1) : 0, h = (NSUB == 2) ? (u >> 1) : u;
       const int kb = k0 + 32 * h;
       const int q_last = qw0 + 32 * sb + min(31, nq_wave - 32 * sb - 1);   // last valid query of the sub-block
       if ((sb == 1 && !hasB) || kb >= klen || (CAUSAL && kb > q_last)) return;   // wave-uniform
@@ -990,8 +995,9 @@ __global__ __launch_bounds__(64 * NW, (D == 64) ? 2 : 1) void attn2_kernel(AttnA
   // leading tiles that are whole (all 64 keys exist) and need no mask for any query of this wave
   const int n_whole = !hasA ? 0 : min(n_tiles, CAUSAL ? max(0, (qw0 + 1) / KB) : klen / KB);
   int kt = 0;
-  if (hasB) {
-    for (; kt < n_whole; ++kt) step(kt, [&](int) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 4>{}); });
+  if (NSUB == 2 && hasB) {
+    if constexpr (NSUB == 2)
+      for (; kt < n_whole; ++kt) step(kt, [&](int) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 4>{}); });
   } else if (hasA) {
     for (; kt < n_whole; ++kt) step(kt, [&](int) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 2>{}); });
   }
@@ -1004,12 +1010,12 @@ __global__ __launch_bounds__(64 * NW, (D == 64) ? 2 : 1) void attn2_kernel(AttnA
     for (int i = 0; i < 12; ++i) d[i] = st_acc[i];
     d[12] = (unsigned long long)n_tiles;
     d[13] = st_prev - st_begin;
-    d[14] = (unsigned long long)((hasA ? 1 : 0) + (hasB ? 1 : 0) + (cls_block ? 4 : 0));
+    d[14] = (unsigned long long)((hasA ? 1 : 0) + ((hasB || (NSUB == 1 && hasA)) ? 1 : 0) + (cls_block ? 4 : 0));
   }
 #endif
   // ---- epilogue: O[query][d] = O^T / l ; lane = query, register r <-> d = 32 dt + (r & 3) + 8 (r >> 2) + 4 hi
 #pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
+  for (int sb = 0; sb < NSUB; ++sb) {
     const float l = xhalf_sum(lsum[sb]);
     const bool ok = cls_block ? (sb == 0 && l31 == 0) : (qi[sb] < len);
     if (!ok) continue;
@@ -1046,22 +1052,22 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
   }
   // round 3: the two-sub-block pipelined kernel (attn2_kernel) for sequences of up to 4096 keys; variant 5 = the round-2 choice
   const bool dma = max_seqlen <= 4096 && g_attn_variant != 4;   // variant 4: the register-staged kernel for EVERY shape
-  if constexpr (D == 64 && !CAUSAL) if (dma && g_attn_variant != 5) {
+  if (dma && g_attn_variant != 5) {
+    constexpr int NSUB = (D == 64) ? 2 : 1;
     auto go = [&](auto nwc, auto soloc) {
       constexpr int NW = decltype(nwc)::value;
       constexpr bool SOLO = decltype(soloc)::value;
+      constexpr int QBW = 32 * NSUB * NW;
       // non-causal launches may peel key / query 0 of a sequence (length = 1 mod 64): one more block for query 0
-      const int nqb2 = CAUSAL ? (max_seqlen + 64 * NW - 1) / (64 * NW)
-                              : std::max((max_seqlen + 64 * NW - 1) / (64 * NW), (max_seqlen - 1 + 64 * NW - 1) / (64 * NW) + 1);
+      const int nqb2 = CAUSAL ? (max_seqlen + QBW - 1) / QBW : std::max((max_seqlen + QBW - 1) / QBW, (max_seqlen - 1 + QBW - 1) / QBW + 1);
       a.n_qb = nqb2;
       const int total2 = nqb2 * a.n_heads * n_seqs;
       const dim3 grid2(8 * ((total2 + 7) / 8));
-      if (a.round_mode == 1) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_DIV, NW, SOLO>), grid2, dim3(64 * NW), 0, s, a);
-      else if (pow2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_POW2, NW, SOLO>), grid2, dim3(64 * NW), 0, s, a);
-      else hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_MUL, NW, SOLO>), grid2, dim3(64 * NW), 0, s, a);
+      if (a.round_mode == 1) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_DIV, NW, SOLO, NSUB>), grid2, dim3(64 * NW), 0, s, a);
+      else if (pow2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_POW2, NW, SOLO, NSUB>), grid2, dim3(64 * NW), 0, s, a);
+      else hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_MUL, NW, SOLO, NSUB>), grid2, dim3(64 * NW), 0, s, a);
     };
     if (g_attn_variant == 6) go(std::integral_constant<int, 2>{}, std::false_type{});
-    else if (g_attn_variant == 7) go(std::integral_constant<int, 4>{}, std::true_type{});
     else go(std::integral_constant<int, 4>{}, std::false_type{});
     return mjv_check_launch("attention");
   }
@@ -1090,8 +1096,8 @@ extern "C" int mjv_attention_stamp_buffer(void* p) {
 #endif
 
 extern "C" int mjv_attention_set_variant(int32_t v) {
-  if (v < 0 || v > 7) {   // 0 = production; 1-3 = the timing experiments documented at attn_kernel; 4 = the register-staged kernel of round 1 (A/B)
-    mjv_set_error("attention_set_variant: %d not in {0..7}", v);
+  if (v < 0 || v > 6) {   // 0 = production; 1-3 = the timing experiments documented at attn_kernel; 4 = the register-staged kernel of round 1 (A/B)
+    mjv_set_error("attention_set_variant: %d not in {0..6}", v);
     return MJV_E_ARG;
   }
   g_attn_variant = v;

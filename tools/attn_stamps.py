@@ -39,7 +39,7 @@ def run(name, n_seq, L, H, G, D, causal, mode, nw=4):
     torch.cuda.synchronize()
     lib.mjv_attention_stamp_buffer(None)
     b = buf.view(-1, 16).cpu().numpy()
-    for kind, label in ((2, "waves with two sub-blocks"), (5, "query-0 block (one sub-block)")):
+    for kind, label in ((2, "full waves"), (5, "query-0 block (one sub-block)")):
         rows = b[(b[:, 14] == kind) & (b[:, 12] > 0)]
         if not len(rows):
             continue
@@ -51,5 +51,4 @@ def run(name, n_seq, L, H, G, D, causal, mode, nw=4):
 
 
 run("vit_d64", 64, 1025, 16, 1, 64, False, 0)
-if len(sys.argv) > 1:
-    run("d64_L1024", 64, 1024, 16, 1, 64, False, 0)
+run("llm_d128c", 8, 2186, 16, 2, 128, True, 1)
