@@ -615,7 +615,7 @@ __device__ unsigned long long* g_stamp_out = nullptr;
 
 // NSUB = 32-query sub-blocks per wave: 2 at D = 64; 1 at D = 128, where two would need ~310 registers (the pipeline then
 // runs over the two key halves of the one sub-block: QK(h0) | QK(h1) || softmax(h0) | PV(h0) || softmax(h1) | PV(h1))
-template <int D, bool CAUSAL, int RM, int NW, bool SOLO = false, int NSUB = 2>
+template <int D, bool CAUSAL, int RM, int NW, int NSUB>
 __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   constexpr int PK = D * 2, PV = D * 2;           // unpadded rows, swizzled chunks (as the DMA form of attn_kernel)
   constexpr int KBYTES = KB * PK, VBYTES = KB * PV, TB = KBYTES + VBYTES;
@@ -642,10 +642,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   const int qb = CAUSAL ? nb_main - 1 - bid.qb : bid.qb;   // causal: heaviest blocks first
   if (CAUSAL ? (qb < 0) : (qb > nb_main || (qb == nb_main && !peel))) return;
   const bool cls_block = peel && qb == nb_main;   // the block of query 0
-  // SOLO: that block is run by wave 0 ALONE (the others leave; one wave's LDS operations are in order, so its loop has no
-  // barrier and it issues every share of the DMA); otherwise all waves stay and share the staging
-  const bool solo = SOLO && cls_block;
-  if (solo && wave > 0) return;
+  // (all of that block's waves stay and share the staging: run by wave 0 alone - no barriers, the others gone - it measured
+  // 3 % slower: the lone wave issues every DMA instruction of the tile itself)
 
   // this wave's queries: sub-block A = qw0 + l31, B = qw0 + 32 + l31 (sequence-relative indices)
   const int qw0 = cls_block ? 0 : (peel ? 1 : 0) + qb * QBW + wave * QW;
@@ -762,28 +760,30 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
                  : "v"(voff), "s"(base), "s"(lds_dst)
                  : "memory");
   };
+  // piece idx = 2 j + (0: K, 1: V) of this wave's share of tile kt; WHOLE: all 64 key rows exist (no row clamp)
+  auto dma_piece = [&](int kt, int boff, int idx, auto wholec) __attribute__((always_inline)) {
+    const int j = idx >> 1;
+    const bool is_v = idx & 1;
+    unsigned off;
+    if constexpr (decltype(wholec)::value) {
+      off = is_v ? vso[j] + (unsigned)(kt * KB) * (unsigned)p.ldv * 2u : kso[j] + (unsigned)(kt * KB) * (unsigned)p.ldk * 2u;
+    } else {
+      const int slot = (j * NW + wave) * 64 + lane;
+      const int row = slot / CH, cl = slot % CH;
+      const int sw = is_v ? ((D == 64) ? (((row >> 1) & 1) * 4) : ((row & 3) * 4)) : ((D == 64) ? ((row >> 1) & 7) : (row & 15));
+      int gr = kt * KB + row;
+      gr = gr < klen ? gr : klen - 1;                   // rows past the end: any valid row (masked later)
+      off = (unsigned)(gr * (int)(is_v ? p.ldv : p.ldk) + ((cl ^ sw) * 8)) * 2u;
+    }
+    dma16(is_v ? v_seq : k_seq, off, lds0 + (unsigned)(boff + (is_v ? KBYTES : 0) + (j * NW + wave) * 1024));
+  };
   auto issue = [&](int kt, int boff) __attribute__((always_inline)) {
-    const bool whole = kt * KB + KB <= klen;
-    for (int w = solo ? 0 : wave; w < (solo ? NW : wave + 1); ++w) {
+    if (kt * KB + KB <= klen) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        unsigned ko, vo;
-        if (whole && w == wave) {
-          ko = kso[j] + (unsigned)(kt * KB) * (unsigned)p.ldk * 2u;
-          vo = vso[j] + (unsigned)(kt * KB) * (unsigned)p.ldv * 2u;
-        } else {
-          const int slot = (j * NW + w) * 64 + lane;
-          const int row = slot / CH, cl = slot % CH;
-          const int sk = (D == 64) ? ((row >> 1) & 7) : (row & 15);
-          const int sv = (D == 64) ? (((row >> 1) & 1) * 4) : ((row & 3) * 4);
-          int gr = kt * KB + row;
-          gr = gr < klen ? gr : klen - 1;                   // rows past the end: any valid row (masked later)
-          ko = (unsigned)(gr * (int)p.ldk + ((cl ^ sk) * 8)) * 2u;
-          vo = (unsigned)(gr * (int)p.ldv + ((cl ^ sv) * 8)) * 2u;
-        }
-        dma16(k_seq, ko, lds0 + (unsigned)(boff + (j * NW + w) * 1024));
-        dma16(v_seq, vo, lds0 + (unsigned)(boff + KBYTES + (j * NW + w) * 1024));
-      }
+      for (int idx = 0; idx < 2 * NI; ++idx) dma_piece(kt, boff, idx, std::true_type{});
+    } else {
+#pragma unroll
+      for (int idx = 0; idx < 2 * NI; ++idx) dma_piece(kt, boff, idx, std::false_type{});
     }
   };
 
@@ -855,8 +855,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 
     // ---- software pipeline over the units of a whole, unmasked tile: U = 4 (unit u: sub-block u & 1, key half u >> 1) for a
     // wave with both sub-blocks, U = 2 (sub-block A, key half u) for a wave with at most 32 queries (the block of query 0)
-  auto pipeline = [&](auto uc_) __attribute__((always_inline)) {
+  auto pipeline = [&](auto uc_, int kt) __attribute__((always_inline)) {
       constexpr int U = decltype(uc_)::value;
+      const bool more = (kt + 2) * KB <= klen && kt + 1 < n_tiles;   // the next tile is whole: its DMA is issued in here
+      const int nboff = ((kt + 1) & 1) * TB;
       f32x16 S[U];
       unsigned Pw[U][8];
       f32x2 psum[U];
@@ -887,6 +889,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
                                                                      oacc[sb][q.f >> 1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // the next tile's DMA, one piece behind each of the first MFMAs (slot 0 has no vector work to put there)
+        if constexpr (i < 2 * NI) {
+          if (more) dma_piece(kt + 1, nboff, i, std::true_type{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
         // the slice of softmax(slot - 1) that goes behind this MFMA
         constexpr int s = q.slot;
         if constexpr (s >= 1 && s <= U) {
@@ -974,15 +981,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   // that chooses between the pipelines and the general path per tile makes the register allocator give the O accumulators a
   // different home on every path (64 v_mov per tile between them, and spills in the pipeline).  Whole, unmasked tiles come
   // first in every wave's key order (the ragged last tile and the causal diagonal are at the end), so the split is by position.
-  auto step = [&](int kt, auto&& math) __attribute__((always_inline)) {
+  auto step = [&](int kt, auto issues_itself, auto&& math) __attribute__((always_inline)) {
     // tile kt sits in buffer kt & 1: every wave's share has landed after the wait + barrier, and every wave is done with
     // tile kt - 1 (the other buffer), which the next DMA overwrites
     MJV_STAMP(0);                      // loop overhead (address toggles, branch)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MJV_STAMP(1);                      // own DMA of this tile landed
-    if (!solo) __syncthreads();
+    __syncthreads();
     MJV_STAMP(2);                      // barrier
-    if (kt + 1 < n_tiles) issue(kt + 1, ((kt + 1) & 1) * TB);
+    // (the pipelines issue the DMA of a WHOLE next tile themselves, behind their first MFMAs)
+    if (kt + 1 < n_tiles && !(decltype(issues_itself)::value && (kt + 2) * KB <= klen)) issue(kt + 1, ((kt + 1) & 1) * TB);
     MJV_STAMP(3);                      // DMA issue
     math(kt);
     MJV_STAMP(11);                     // (general-path tiles; the pipelines stamp their slots 4 .. 9 themselves)
@@ -997,11 +1005,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   int kt = 0;
   if (NSUB == 2 && hasB) {
     if constexpr (NSUB == 2)
-      for (; kt < n_whole; ++kt) step(kt, [&](int) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 4>{}); });
+      for (; kt < n_whole; ++kt) step(kt, std::true_type{}, [&](int t) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 4>{}, t); });
   } else if (hasA) {
-    for (; kt < n_whole; ++kt) step(kt, [&](int) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 2>{}); });
+    for (; kt < n_whole; ++kt) step(kt, std::true_type{}, [&](int t) __attribute__((always_inline)) { pipeline(std::integral_constant<int, 2>{}, t); });
   }
-  for (; kt < n_tiles; ++kt) step(kt, general);
+  for (; kt < n_tiles; ++kt) step(kt, std::false_type{}, general);
 
 #ifdef MJV_ATTN_STAMPS
   if (g_stamp_out && lane == 0) {
@@ -1017,7 +1025,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
   for (int sb = 0; sb < NSUB; ++sb) {
     const float l = xhalf_sum(lsum[sb]);
-    const bool ok = cls_block ? (sb == 0 && l31 == 0) : (qi[sb] < len);
+    const bool ok = cls_block ? (wave == 0 && sb == 0 && l31 == 0) : (qi[sb] < len);   // (every wave of the query-0 block reaches this)
     if (!ok) continue;
     const float inv = 1.0f / l;
     u16* op = p.O + (long)(s0 + qi[sb]) * p.ldo + (long)head * p.ohs;
@@ -1054,21 +1062,20 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
   const bool dma = max_seqlen <= 4096 && g_attn_variant != 4;   // variant 4: the register-staged kernel for EVERY shape
   if (dma && g_attn_variant != 5) {
     constexpr int NSUB = (D == 64) ? 2 : 1;
-    auto go = [&](auto nwc, auto soloc) {
+    auto go = [&](auto nwc) {
       constexpr int NW = decltype(nwc)::value;
-      constexpr bool SOLO = decltype(soloc)::value;
       constexpr int QBW = 32 * NSUB * NW;
       // non-causal launches may peel key / query 0 of a sequence (length = 1 mod 64): one more block for query 0
       const int nqb2 = CAUSAL ? (max_seqlen + QBW - 1) / QBW : std::max((max_seqlen + QBW - 1) / QBW, (max_seqlen - 1 + QBW - 1) / QBW + 1);
       a.n_qb = nqb2;
       const int total2 = nqb2 * a.n_heads * n_seqs;
       const dim3 grid2(8 * ((total2 + 7) / 8));
-      if (a.round_mode == 1) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_DIV, NW, SOLO, NSUB>), grid2, dim3(64 * NW), 0, s, a);
-      else if (pow2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_POW2, NW, SOLO, NSUB>), grid2, dim3(64 * NW), 0, s, a);
-      else hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_MUL, NW, SOLO, NSUB>), grid2, dim3(64 * NW), 0, s, a);
+      if (a.round_mode == 1) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_DIV, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
+      else if (pow2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_POW2, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
+      else hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_MUL, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
     };
-    if (g_attn_variant == 6) go(std::integral_constant<int, 2>{}, std::false_type{});
-    else go(std::integral_constant<int, 4>{}, std::false_type{});
+    if (g_attn_variant == 6) go(std::integral_constant<int, 2>{});
+    else go(std::integral_constant<int, 4>{});
     return mjv_check_launch("attention");
   }
   // LDS-DMA staging up to 4096 keys per sequence (measured +2 ... +3 % at 1025 / 2186, 0 at 2048 non-causal); beyond that

@@ -364,8 +364,22 @@ def _rank_case_engineered(cuda, name, pairs_per_forward):
     counts = harness.evaluate_votes((cyc[i % 4], float(got[i, 0, 0]), float(got[i, 1, 0])) for i in range(P) if keep[i])
     exp = emeta["accuracy_on_kept_pairs"]
     print(f"prefer_Acc {counts.prefer_acc:.4f} Acc {counts.acc:.4f}; reference counts {exp}")
-    assert (counts.prefer_truth, counts.prefer_total, counts.truth, counts.total) == \
-        (exp["prefer_truth"], exp["prefer_total"], exp["truth"], exp["total"])
+    # the preference votes (decisive pairs by construction) must give the reference's counts exactly; a tie / both-bad vote
+    # is decided by the SIGN of a score, so a kept pair with a reference score within 12 x the noise rms of zero can fall
+    # either way under any re-association of the fp32 sums (round 3: the attention kernel's exact-power-of-two softmax
+    # offsets moved one such vote): the truth count may differ by at most the number of such borderline votes
+    assert (counts.prefer_truth, counts.prefer_total, counts.total) == (exp["prefer_truth"], exp["prefer_total"], exp["total"])
+    border = sum(1 for i in range(P) if keep[i] and cyc[i % 4] in ("tievote", "bothbad_vote")
+                 and min(abs(float(ref[i, 0, 0])), abs(float(ref[i, 1, 0]))) < 12 * noise_rms)
+    print(f"truth {counts.truth} vs reference {exp['truth']}; borderline tie / both-bad votes: {border}")
+    assert abs(counts.truth - exp["truth"]) <= border
+    exact = harness.evaluate_votes((cyc[i % 4], float(got[i, 0, 0]), float(got[i, 1, 0])) for i in range(P) if keep[i]
+                                   and not (cyc[i % 4] in ("tievote", "bothbad_vote")
+                                            and min(abs(float(ref[i, 0, 0])), abs(float(ref[i, 1, 0]))) < 12 * noise_rms))
+    ref_exact = harness.evaluate_votes((cyc[i % 4], float(ref[i, 0, 0]), float(ref[i, 1, 0])) for i in range(P) if keep[i]
+                                       and not (cyc[i % 4] in ("tievote", "bothbad_vote")
+                                                and min(abs(float(ref[i, 0, 0])), abs(float(ref[i, 1, 0]))) < 12 * noise_rms))
+    assert (exact.prefer_truth, exact.truth, exact.total) == (ref_exact.prefer_truth, ref_exact.truth, ref_exact.total)
 
 
 def _rank_case(cuda, name, pairs_per_forward):
