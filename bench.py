@@ -7,11 +7,11 @@
 Called WITHOUT a launcher and with --gpus N > 1 it starts the N ranks itself (a child `python -m torch.distributed.run`
 on 127.0.0.1, started before this process touches a GPU; the parent only waits and passes rank 0's JSON line through).
 
-One "step" = one pass of the reward-scoring hot path over one batch of synthetic pairs per GPU
-(BASELINE.json configs[1]: 4 pairs = 8 videos x 8 tiles, N = 2186 tokens per video), inputs already
-resident in HBM, random-init weights of the exact MJ-VIDEO-2B architecture.  Pairs are sharded
-data-parallel (weak scaling: every rank scores its own 4 pairs per step); the only collective is one
-RCCL all-gather of the [pairs, 2, 34] fp32 score block per step.
+One "step" = one pass of the reward-scoring hot path over one batch of synthetic pairs, inputs already resident in
+HBM, random-init weights of the exact MJ-VIDEO-2B architecture.  --gpus 1: BASELINE.json configs[1] (4 pairs = 8 videos
+x 8 tiles @448^2, N = 2186 tokens per video).  --gpus N > 1: BASELINE.json configs[2]'s shard size, 8 pairs per GPU per
+step (64 pairs at 8 GPUs), weak scaling; the step goes through mj_video_amd.parallel.score_pairs_dp, whose only
+collective is one RCCL all-gather of the [pairs, 2, 34] fp32 score block.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   "roofline":     dominant kernel's algorithmic TFLOP/s (HIP events on the launch stream, recorded inside the
@@ -111,12 +111,36 @@ def cpu_baseline(image_size, n_tiles, threads, iters=2):
 METRIC = "video-pairs scored/sec, MJ-VIDEO-2B 8-frame bf16, 1/2/4/8 MI355X"   # BASELINE.json "metric", verbatim
 
 
+def dp_step(score_local, global_pairs, device):
+    """One step of the benchmark at any N: the batch's pairs are sharded over the ranks by ``parallel.score_pairs_dp`` (the
+    product's one collective: an all-gather of the [pairs, 2, 34] fp32 block) and every rank ends up with the whole block in
+    pair order.  ``score_local(local_pair_ids) -> [n_local, 2, 34]``.  Without a process group it is a plain call.
+    (tests/test_dp_gloo.py runs this very function at world size 2 over gloo.)"""
+    from mj_video_amd import parallel
+    return parallel.score_pairs_dp(score_local, global_pairs, device=device)
+
+
+def kernel_sources_sha1():
+    """SHA-1 over the kernel sources: the PMC traffic file names the sources it was measured on (tools/pmc_summary.py writes
+    the same hash), and a file measured on other sources is not quoted."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mj-video_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=4, help="pairs per GPU per step (BASELINE.json configs[1]: 4)")
+    ap.add_argument("--pairs", type=int, default=None,
+                    help="pairs per GPU per step; default 4 at --gpus 1 (BASELINE.json configs[1]: batch = 4 pairs on 1 MI355X) and "
+                         "8 at --gpus N > 1 (configs[2]: batch = 64 pairs sharded DP over 8 MI355X = 8 pairs per GPU)")
     ap.add_argument("--image-size", type=int, default=448)
     ap.add_argument("--frames", type=int, default=8, help="tiles per video (frames x tiles per frame; configs[3]: 16 x 7 = 112)")
     ap.add_argument("--gemm-code", type=int, action="append", default=[],
@@ -128,6 +152,8 @@ def main():
                          "per-kernel statistics)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
+    if args.pairs is None:
+        args.pairs = 4 if args.gpus == 1 else 8
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # No launcher: start the N ranks as fresh children (one process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE
@@ -162,7 +188,7 @@ def main():
     model.config.pad_token_id = synth.PAD_ID
     model.model.img_context_token_id = synth.IMG_CONTEXT_ID
     model.eval()
-    for code in args.gemm_code:
+    for code in args.gemm_code:   # (bench build of the library only: MJV_LIBRARY=.../libmjv_hip_bench.so)
         ops.gemm_set_tile(code)
 
     n_videos = 2 * args.pairs
@@ -176,17 +202,18 @@ def main():
     ids, mask = synth.pad_batch(ids_list)
     ids, mask = ids.to(dev), mask.to(dev)
     seq_len = int(ids.shape[1])
-    gathered = torch.empty(world * n_videos, 34, dtype=torch.float32, device=dev) if world > 1 else None
+    global_pairs = list(range(world * args.pairs))   # pair ids of the whole batch; rank r owns a contiguous block of them
+
+    def score_local(local_pairs):
+        # this rank's shard (its own synthetic inputs, resident in HBM).  Fresh id / mask tensors every step, as every real
+        # batch brings: the forward pays its device->host copy of the ids (the model caches the host copy only for the
+        # SAME unmodified tensor objects)
+        assert len(local_pairs) == args.pairs
+        model.forward(px, ids.clone(), mask.clone())
+        return model.last_packed34.view(args.pairs, 2, 34)
 
     def step():
-        # fresh id / mask tensors every step, as every real batch brings: the forward pays its device->host copy of the
-        # ids (the model caches the host copy only for the SAME unmodified tensor objects)
-        model.forward(px, ids.clone(), mask.clone())
-        block = model.last_packed34
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, block)
-            return gathered
-        return block
+        return dp_step(score_local, global_pairs, dev)
 
     def fence():
         torch.cuda.synchronize()
@@ -241,8 +268,14 @@ def main():
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
-            "config": {"workload": f"MJ-VIDEO-2B, batch={args.pairs} pairs per GPU, {F} frames @{S}^2 max_num=1, "
-                                   f"N={seq_len} tokens/video, random-init weights, inputs resident in HBM",
+            "config": {"workload": (f"MJ-VIDEO-2B, batch={args.pairs * world} pairs"
+                                    + (f" sharded DP over {world} MI355X ({args.pairs} pairs per GPU), RCCL all-gather rewards"
+                                       if world > 1 else " on 1 MI355X")
+                                    + f", {F} frames @{S}^2 max_num=1, N={seq_len} tokens/video, random-init weights, inputs "
+                                      "resident in HBM"),
+                       "baseline_config": ("configs[1]" if (world, args.pairs, S, F) == (1, 4, 448, 8) else
+                                           "configs[2] shard size (8 pairs per GPU; 64 pairs at 8 GPUs)"
+                                           if (args.pairs, S, F) == (8, 448, 8) and world > 1 else "other"),
                        "pairs_per_gpu_per_step": args.pairs, "global_pairs_per_step": args.pairs * world,
                        "ids": "fresh id / mask tensors every step (one device->host copy of the ids per forward)",
                        "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
@@ -252,10 +285,15 @@ def main():
         if prof:
             res = ops.prof_results()
 
-            traffic = {}
+            traffic, traffic_note = {}, None
             tpaths = sorted(p_ for p_ in os.listdir(os.path.join(ROOT, "profiles")) if p_.endswith("_pmc_traffic.json"))
-            if (S, F, args.pairs) == (448, 8, 4) and tpaths:   # the latest round's committed PMC passes
-                traffic = json.load(open(os.path.join(ROOT, "profiles", tpaths[-1]))).get("per_launch_bytes", {})
+            if (S, F, args.pairs) == (448, 8, 4) and tpaths:   # the latest round's committed PMC passes of this workload
+                tj = json.load(open(os.path.join(ROOT, "profiles", tpaths[-1])))
+                if tj.get("source_sha1") == kernel_sources_sha1():
+                    traffic = tj.get("per_launch_bytes", {})
+                else:   # kernels changed since the counters were collected: a stale figure is worse than none
+                    traffic_note = (f"profiles/{tpaths[-1]} was measured on other kernel sources (source_sha1 differs): "
+                                    "not quoted; re-run tools/collect_profiles.sh")
 
             def roofline(res, steps, share_from=None):
                 share_from = share_from or res
@@ -266,7 +304,7 @@ def main():
                         "unit": "TFLOP/s", "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4),
                         # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same workload
                         # (profiles/rNN_pmc_traffic.json; a PMC run cannot be nested inside this process)
-                        "traffic": traffic.get(name),
+                        "traffic": traffic.get(name), **({"traffic_note": traffic_note} if traffic_note else {}),
                         "algorithmic_bytes_per_launch": round(r["bytes"] / max(r["launches"], 1)),
                         "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(r["launches"], 1), 4),
                         "share_of_kernel_time": round(share_from[name]["ms"] / tot, 4) if tot else None}

@@ -13,7 +13,10 @@
  *   - bf16 tensors are passed as `const uint16_t*` (raw bf16 bit patterns), row-major, with an explicit
  *     leading dimension in ELEMENTS;
  *   - every call only ENQUEUES on `stream` (a hipStream_t passed as void*; 0 = null stream) and never
- *     synchronises; the library is stateless apart from the opt-in profiler, hence thread-safe per stream;
+ *     synchronises; the library keeps no setting between calls (ABI 4: what a caller may choose - the tile kernel of a
+ *     GEMM, the attention kernel - travels in the call's descriptor; there is no process-wide setter), so calls from
+ *     different threads on different streams do not interact; the only shared state is the opt-in profiler (mutex);
+ *     the measurement switches of earlier ABI versions live in the separate bench build (include/mjv_bench.h);
  *   - return value 0 = ok, negative = error (MJV_E_*); `mjv_last_error()` gives a thread-local message.
  *   - rounding points follow the reference's bf16 eager path (bf16 result after every torch op).
  */
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MJV_ABI_VERSION 3
+#define MJV_ABI_VERSION 4
 
 enum {
   MJV_OK = 0,
@@ -84,6 +87,10 @@ typedef struct mjv_gemm_desc {
                                        flight; lets under-filled launches split K (fp32 partial tiles, summed in a fixed
                                        order: results stay deterministic).  NULL: never split.  mjv_gemm_workspace_bytes() */
   int64_t workspace_bytes;
+  int32_t tile;                     /* 0 = automatic (256x256 8-wave kernel for M >= 512 and N >= 256; else the 64x32 skinny
+                                       kernel up to 128 rows, 128x128 above); 64 / 128 / 256 force one kernel - every choice
+                                       computes the same roundings, only the fp32 summation order differs (the parity tests
+                                       run every case on all three) */
   /* MJV_EPI_ROPE_QKV only */
   const mjv_bf16 *rope_cos, *rope_sin;   /* [positions][128] tables (bf16, modeling_internlm2.py:147-180) */
   const int32_t* rope_pos;               /* [M] position of every row (device) */
@@ -96,18 +103,6 @@ typedef struct mjv_gemm_desc {
 int64_t mjv_gemm_workspace_bytes(void);
 
 int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);
-/* tile selection: 0 = automatic (256x256 8-wave kernel for M >= 512 and N >= 256; else 64x32 skinny kernel up to 128
- * rows, 128x128 above), 64 / 128 / 256 force one kernel (used by the parity tests to cover all three on every shape).
- * 6000 + m: largest M the skinny kernel takes (6000 = never; A/B measurements).  Measurement switches, process-wide, never needed
- * for results: 4000 / 4001 split-K of 128-tile launches off / on, 4200 / 4201 K-sliced 256-tile launches (under-filled problems
- * with K >= 4096) off / on, 4100 + s caps the slices per tile at s (1..8), 4300 + n sets the fewest K-tiles per 256-tile slice,
- * 2000 + g forces the group-M of the tile order (2000 = chosen per shape: 5 for K <= 1024, 4 for K >= 8192 or N >= 8192, else 8),
- * 1000 / 1003 / 1004 select the 256-tile kernel's timing variants (1003: no epilogue, 1004: no
- * global stores - wrong results by construction, tools/gemm_bench.py only). */
-int mjv_gemm_set_tile(int32_t tile);
-/* diagnostic build of the 256-tile kernel (tile code 1006): wave 0 of every workgroup writes 8 x uint64 s_memtime values
- * {start stamp, prologue, main loop, epilogue pass A, epilogue pass B, total cycles} to this device buffer; NULL = off */
-int mjv_gemm_stamp_buffer(void* device_buffer);
 
 /* ---------------------------------------------------------------------------------------------
  * Flash-style attention over packed variable-length sequences (no N x N scores in HBM).
@@ -129,17 +124,15 @@ typedef struct mjv_attn_desc {
   int32_t causal;
   float scale;
   int32_t score_round_mode;
+  int32_t kernel;             /* 0 = automatic (round 3: the two-sub-block pipelined kernel up to 4096 keys per sequence, the
+                                 register-staged round-1 kernel beyond); 4 = the register-staged kernel for every shape;
+                                 5 = the round-2 choice (its LDS-DMA form up to 4096 keys).  All three give correct results:
+                                 the tests A/B them.  Other values: MJV_E_ARG */
 } mjv_attn_desc;
 
 int mjv_attention_bf16(const mjv_attn_desc* d, void* stream);
-/* timing-experiment selector (tools/attn_bench.py; process-wide, never needed for results): 0 = production; on the two
- * production shapes (D = 64 non-causal with a power-of-two scale, D = 128 causal mode 1) 1 = K/V staged once (no
- * barriers / LDS stores / global loads after the first tile), 2 = softmax removed, 3 = MFMAs removed - wrong results by
- * construction, they attribute the kernel's time; 4 = the register-staged kernel for every sequence length (correct
- * results; A/B against the LDS-DMA staging that the automatic choice uses for max_seqlen <= 4096).  Other values return MJV_E_ARG.
- * max_seqlen MUST be >= the longest sequence of cu_seqlens: query rows beyond it are not computed (their O rows are
- * left untouched). */
-int mjv_attention_set_variant(int32_t variant);
+/* max_seqlen MUST be >= the longest sequence of cu_seqlens: query rows beyond it are not computed (their O rows are left
+ * untouched). */
 
 /* LayerNorm over the last dim, fp32 statistics, bf16 out (nn.LayerNorm on bf16:
  * modeling_intern_vit.py:291,293; modeling_internvl_chat.py:136).

@@ -1,0 +1,31 @@
+/*
+ * mjv_bench.h - measurement switches of the BENCH build of the library (make -C mj-video_amd/csrc bench ->
+ * mj-video_amd/libmjv_hip_bench.so, compiled with -DMJV_BENCH).  The product library (libmjv_hip.so) exports none of
+ * these and does not contain the kernel variants they select; nothing under mj-video_amd/ loads the bench build (only
+ * tools/: gemm_bench.py, gemm_stamps.py, attn_bench.py with variant lists).  Process-wide, not thread-safe, and several
+ * of the variants skip work on purpose - wrong results by construction - to attribute a kernel's time.
+ */
+#ifndef MJV_BENCH_H_
+#define MJV_BENCH_H_
+#include "mjv.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GEMM: 0 resets everything.  4000 / 4001 split-K of 128-tile launches off / on; 4200 / 4201 K-sliced 256-tile launches off / on;
+ * 4100 + s caps the slices per tile at s (1..8); 4300 + n sets the fewest K-tiles per 256-tile slice; 2000 + g forces the
+ * group-M of the tile order (2000 = per shape); 6000 + m = largest M the skinny kernel takes (6000 = never);
+ * 1000 / 1003 / 1004 / 1006 select the 256-tile kernel's variants (1003: no epilogue, 1004: no global stores - wrong results;
+ * 1006: s_memtime stamps of wave 0 to the stamp buffer). */
+int mjv_bench_gemm_set(int32_t code);
+/* 1006: wave 0 of every workgroup writes 8 x uint64 {start stamp, prologue, main loop, epilogue pass A, pass B, total
+ * cycles} to this device buffer; NULL = off */
+int mjv_bench_gemm_stamp_buffer(void* device_buffer);
+/* attention: 0 = production; on the two production shapes of the round-2 kernel (desc.kernel = 5) 1 = K/V staged once,
+ * 2 = softmax removed, 3 = MFMAs removed - wrong results; 6 = attn2_kernel with two waves per workgroup (correct). */
+int mjv_bench_attention_set(int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJV_BENCH_H_ */

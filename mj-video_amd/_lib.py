@@ -22,7 +22,7 @@ class MjvLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3  # MJV_ABI_VERSION of include/mjv.h
+ABI_VERSION = 4  # MJV_ABI_VERSION of include/mjv.h
 
 
 class GemmDesc(C.Structure):
@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
                 ("epilogue", C.c_int32), ("bias", C.c_void_p), ("scale", C.c_void_p), ("res", C.c_void_p),
                 ("ldr", C.c_int64), ("res_mod", C.c_int32), ("res_off", C.c_int32), ("out_group", C.c_int32),
                 ("out_pad", C.c_int32), ("out_rows", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_int64), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("workspace_bytes", C.c_int64), ("tile", C.c_int32), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("rope_pos", C.c_void_p), ("rope_q", C.c_void_p), ("rope_k", C.c_void_p), ("rope_ldq", C.c_int64),
                 ("rope_ldk", C.c_int64), ("rope_group", C.c_int32)]
 
@@ -43,7 +43,7 @@ class AttnDesc(C.Structure):
                 ("o_head_stride", C.c_int32), ("cu_seqlens", C.c_void_p), ("n_seqs", C.c_int32),
                 ("max_seqlen", C.c_int32), ("n_heads", C.c_int32), ("kv_group", C.c_int32),
                 ("head_dim", C.c_int32), ("causal", C.c_int32), ("scale", C.c_float),
-                ("score_round_mode", C.c_int32)]
+                ("score_round_mode", C.c_int32), ("kernel", C.c_int32)]
 
 
 class HeadsDesc(C.Structure):
@@ -66,10 +66,7 @@ SYMBOLS = {
     "mjv_arch": (C.c_char_p, []),
     "mjv_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _VP]),
     "mjv_gemm_workspace_bytes": (C.c_int64, []),
-    "mjv_gemm_set_tile": (C.c_int, [_I32]),
-    "mjv_gemm_stamp_buffer": (C.c_int, [_VP]),
     "mjv_attention_bf16": (C.c_int, [C.POINTER(AttnDesc), _VP]),
-    "mjv_attention_set_variant": (C.c_int, [_I32]),
     "mjv_layernorm_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, _F, _I32, _VP]),
     "mjv_rmsnorm_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, _F, _VP]),
     "mjv_rope_split_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
@@ -87,6 +84,14 @@ SYMBOLS = {
     "mjv_prof_get": (C.c_int, [_I32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
+
+# include/mjv_bench.h: exported by the BENCH build only (libmjv_hip_bench.so; tools/ load it by pointing MJV_LIBRARY at it)
+BENCH_SYMBOLS = {
+    "mjv_bench_gemm_set": (C.c_int, [_I32]),
+    "mjv_bench_gemm_stamp_buffer": (C.c_int, [_VP]),
+    "mjv_bench_attention_set": (C.c_int, [_I32]),
+}
+BENCH_LIB_PATH = os.path.join(_PKG_DIR, "libmjv_hip_bench.so")
 
 _lock = threading.Lock()
 _lib = None
@@ -111,20 +116,25 @@ def load_library():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.isfile(LIB_PATH):
+        path = os.environ.get("MJV_LIBRARY") or LIB_PATH   # (tools: the bench / stamp builds of the same sources)
+        if not os.path.isfile(path):
             raise MjvLibraryError(
-                f"{LIB_PATH} not found: the HIP extension is required (python -c 'import __graft_entry__ as g; "
+                f"{path} not found: the HIP extension is required (python -c 'import __graft_entry__ as g; "
                 f"g.build()' or make -C {CSRC_DIR}); there is no CPU fallback")
         try:
-            lib = C.CDLL(LIB_PATH)
+            lib = C.CDLL(path)
         except OSError as e:
-            raise MjvLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+            raise MjvLibraryError(f"cannot load {path}: {e}") from e
         for name, (res, args) in SYMBOLS.items():
             try:
                 fn = getattr(lib, name)
             except AttributeError as e:
-                raise MjvLibraryError(f"{LIB_PATH} does not export {name}") from e
+                raise MjvLibraryError(f"{path} does not export {name}") from e
             fn.restype, fn.argtypes = res, args
+        for name, (res, args) in BENCH_SYMBOLS.items():   # present in the bench build only
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
         if lib.mjv_abi_version() != ABI_VERSION:
             raise MjvLibraryError(f"ABI version mismatch: library {lib.mjv_abi_version()} != binding {ABI_VERSION}")
         _lib = lib

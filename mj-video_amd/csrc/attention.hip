@@ -1042,25 +1042,29 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 
 }  // namespace v2
 
-int g_attn_variant = 0;
+#ifdef MJV_BENCH
+int g_attn_bench = 0;   // bench library only (mjv_bench_attention_set): timing variants 1-3 of the round-2 kernel, 6 = NW 2
+#endif
 
 template <int D, bool CAUSAL>
-int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
+int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
   int e;
   const bool pow2 = a.round_mode == 0 && frexpf(a.scale, &e) == 0.5f;
   a.n_seqs = n_seqs;
   a.n_qb = (max_seqlen + QB - 1) / QB;
   const int total = a.n_qb * a.n_heads * n_seqs;
   const dim3 grid(8 * ((total + 7) / 8));
+#ifdef MJV_BENCH
   if constexpr ((D == 64 && !CAUSAL) || (D == 128 && CAUSAL)) {   // timing experiments on the two production shapes
     constexpr int RMX = (D == 64) ? RM_POW2 : RM_DIV;
-    if (g_attn_variant == 1) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 1>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
-    if (g_attn_variant == 2) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 2>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
-    if (g_attn_variant == 3) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 3>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
+    if (g_attn_bench == 1) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 1>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
+    if (g_attn_bench == 2) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 2>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
+    if (g_attn_bench == 3) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 3>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
   }
+#endif
   // round 3: the two-sub-block pipelined kernel (attn2_kernel) for sequences of up to 4096 keys; variant 5 = the round-2 choice
-  const bool dma = max_seqlen <= 4096 && g_attn_variant != 4;   // variant 4: the register-staged kernel for EVERY shape
-  if (dma && g_attn_variant != 5) {
+  const bool dma = max_seqlen <= 4096 && kernel != 4;   // kernel 4: the register-staged kernel for EVERY shape
+  if (dma && kernel != 5) {
     constexpr int NSUB = (D == 64) ? 2 : 1;
     auto go = [&](auto nwc) {
       constexpr int NW = decltype(nwc)::value;
@@ -1074,8 +1078,11 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, hipStream_t s) {
       else if (pow2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_POW2, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
       else hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_MUL, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
     };
-    if (g_attn_variant == 6) go(std::integral_constant<int, 2>{});
-    else go(std::integral_constant<int, 4>{});
+#ifdef MJV_BENCH
+    if (g_attn_bench == 6) go(std::integral_constant<int, 2>{});
+    else
+#endif
+      go(std::integral_constant<int, 4>{});
     return mjv_check_launch("attention");
   }
   // LDS-DMA staging up to 4096 keys per sequence (measured +2 ... +3 % at 1025 / 2186, 0 at 2048 non-causal); beyond that
@@ -1102,18 +1109,23 @@ extern "C" int mjv_attention_stamp_buffer(void* p) {
 }
 #endif
 
-extern "C" int mjv_attention_set_variant(int32_t v) {
-  if (v < 0 || v > 6) {   // 0 = production; 1-3 = the timing experiments documented at attn_kernel; 4 = the register-staged kernel of round 1 (A/B)
-    mjv_set_error("attention_set_variant: %d not in {0..6}", v);
+#ifdef MJV_BENCH
+// bench library only: 0 = production; 1-3 = timing variants of the round-2 kernel on the two production shapes (K/V staged
+// once / softmax removed / MFMAs removed: wrong results by construction); 6 = attn2_kernel with two waves per workgroup
+extern "C" int mjv_bench_attention_set(int32_t v) {
+  if (v != 0 && v != 1 && v != 2 && v != 3 && v != 6) {
+    mjv_set_error("bench_attention_set: %d not in {0, 1, 2, 3, 6}", v);
     return MJV_E_ARG;
   }
-  g_attn_variant = v;
+  g_attn_bench = v;
   return MJV_OK;
 }
+#endif
 
 extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
   MJV_REQUIRE(d && d->Q && d->K && d->V && d->O && d->cu_seqlens, "attention: null pointer");
   MJV_REQUIRE(d->head_dim == 64 || d->head_dim == 128, "attention: head_dim %d not in {64,128}", d->head_dim);
+  MJV_REQUIRE(d->kernel == 0 || d->kernel == 4 || d->kernel == 5, "attention: kernel %d not in {0, 4, 5}", d->kernel);
   MJV_REQUIRE(d->n_seqs > 0 && d->max_seqlen > 0 && d->n_heads > 0 && d->kv_group > 0, "attention: bad sizes");
   MJV_REQUIRE(d->n_heads % d->kv_group == 0, "attention: n_heads %% kv_group != 0");
   MJV_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "attention: ld alignment");
@@ -1136,11 +1148,11 @@ extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
   const double pairs = (double)d->n_seqs * d->n_heads * (double)d->max_seqlen * d->max_seqlen * (d->causal ? 0.5 : 1.0);
   const double flops = 4.0 * d->head_dim * pairs;
   if (d->head_dim == 64) {
-    if (d->causal) { MjvProfScope ps("attn_d64_causal", s, flops, 0); return launch<64, true>(a, d->n_seqs, d->max_seqlen, s); }
+    if (d->causal) { MjvProfScope ps("attn_d64_causal", s, flops, 0); return launch<64, true>(a, d->n_seqs, d->max_seqlen, d->kernel, s); }
     MjvProfScope ps("attn_d64", s, flops, 0);
-    return launch<64, false>(a, d->n_seqs, d->max_seqlen, s);
+    return launch<64, false>(a, d->n_seqs, d->max_seqlen, d->kernel, s);
   }
-  if (d->causal) { MjvProfScope ps("attn_d128_causal", s, flops, 0); return launch<128, true>(a, d->n_seqs, d->max_seqlen, s); }
+  if (d->causal) { MjvProfScope ps("attn_d128_causal", s, flops, 0); return launch<128, true>(a, d->n_seqs, d->max_seqlen, d->kernel, s); }
   MjvProfScope ps("attn_d128", s, flops, 0);
-  return launch<128, false>(a, d->n_seqs, d->max_seqlen, s);
+  return launch<128, false>(a, d->n_seqs, d->max_seqlen, d->kernel, s);
 }

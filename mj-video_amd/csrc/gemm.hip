@@ -1011,17 +1011,29 @@ __global__ __launch_bounds__(512) void splitk_finish256_kernel(GemmArgs p) {
 
 }  // namespace t256
 
-int g_force_tile = 0;  // 0 = auto, 128, 256 (tests)
 thread_local int g_num_cus = 256;   // CUs of the device of the call in flight (mjv_device_cus), set in mjv_gemm_bf16
-int g_gm = 0;   // group-M of the 256-tile order: 0 = by shape (pick_gm), tile codes 2000 + gm force one value (tuning)
-int g_skinny_max_m = 128;   // problems with at most this many rows run on the 64 x 32 kernel (tile codes 6000 + m; 6000 = off)
-int g_split_max = 8;  // cap on the slices per tile (tile codes 4100 + cap, experiments)
-int g_split_k = 1;  // 1 = split-K for under-filled 128-tile launches when the caller gives a workspace (tile codes 4001 / 4000)
-int g_variant = 0;
-void* g_stamp_buffer = nullptr;  // variant 6: device buffer for the s_memtime stamps (mjv_gemm_stamp_buffer)  // experimental kernel variant (A/B in one process): tile codes 1000 + v select it
 
-int g_split256_min_kt = 8;   // fewest K-tiles per slice (tile codes 4300 + n, experiments)
-int g_split256 = 1;   // 1 = under-filled problems with deep K run as split-K slices of 256 x 256 tiles (tile codes 4201 / 4200)
+// Measurement knobs.  The product library (default build) has none: the values below are constants, the kernel variants that
+// skip work (wrong results by construction) are not compiled, and what a caller may choose - the tile kernel, for parity
+// tests - travels in the call's descriptor (mjv_gemm_desc.tile).  -DMJV_BENCH (make bench -> libmjv_hip_bench.so, loaded by
+// tools/gemm_bench.py and friends) turns them into process-wide settings behind mjv_bench_gemm_set().
+struct GemmTune {
+  int gm = 0;               // group-M of the 256-tile order: 0 = by shape (pick_gm)
+  int skinny_max_m = 128;   // problems with at most this many rows run on the 64 x 32 kernel
+  int split_max = 8;        // cap on the K slices per tile
+  int split_k = 1;          // split-K for under-filled 128-tile launches when the caller gives a workspace
+  int variant = 0;          // 256-tile kernel variant (3: no epilogue, 4: no global stores, 6: s_memtime stamps)
+  int split256_min_kt = 8;  // fewest K-tiles per slice of the K-sliced 256-tile launches
+  int split256 = 1;         // under-filled problems with deep K run as K slices of 256 x 256 tiles
+  void* stamp_buffer = nullptr;
+};
+#ifdef MJV_BENCH
+GemmTune g_tune;
+#define MJV_TUNE(f) (g_tune.f)
+#else
+constexpr GemmTune g_tune_const{};
+#define MJV_TUNE(f) (g_tune_const.f)
+#endif
 
 template <int EPI>
 int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
@@ -1042,9 +1054,11 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
     (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+#ifdef MJV_BENCH
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+#endif
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<MJV_EPI_BIAS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     attr_done.fetch_or(bit, std::memory_order_release);   // racing first calls both set the attributes: idempotent
   }
@@ -1055,13 +1069,16 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
       const int tiles = a.tiles_m * a.tiles_n;
       hipLaunchKernelGGL((t256::gemm256_kernel<MJV_EPI_BIAS, 7>), dim3(tiles * a.split), dim3(512), t256::LDS_BYTES, s, a);
       hipLaunchKernelGGL(t256::splitk_finish256_kernel<EPI>, dim3(tiles * 8), dim3(512), 0, s, a);
-    } else if (g_variant == 6) {
-      a.ws = (float*)g_stamp_buffer;
+    }
+#ifdef MJV_BENCH
+    else if (MJV_TUNE(variant) == 6) {
+      a.ws = (float*)MJV_TUNE(stamp_buffer);
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 6>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
-    } else if (g_variant == 4)
+    } else if (MJV_TUNE(variant) == 4)
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
-    else if (g_variant == 3)
+    else if (MJV_TUNE(variant) == 3)
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+#endif
     else
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
   } else {
@@ -1089,54 +1106,32 @@ static int pick_gm(int N, int K) { return K <= 1024 ? 5 : (K >= 8192 || N >= 819
 
 extern "C" int64_t mjv_gemm_workspace_bytes(void) { return 256L * 262144L; }
 
-extern "C" int mjv_gemm_set_tile(int32_t tile) {
-  if (tile > 4100 && tile <= 4108) {
-    g_split_max = tile - 4100;
-    return MJV_OK;
-  }
-  if (tile >= 6000 && tile <= 6512) {  // 6000 + m: largest M of the skinny kernel (6000 switches it off; A/B measurements)
-    g_skinny_max_m = tile - 6000;
-    return MJV_OK;
-  }
-  if (tile > 4300 && tile <= 4364) {
-    g_split256_min_kt = tile - 4300;
-    return MJV_OK;
-  }
-  if (tile == 4200 || tile == 4201) {  // split-K on 256 x 256 tiles off / on (A/B measurements)
-    g_split256 = tile - 4200;
-    return MJV_OK;
-  }
-  if (tile == 4000 || tile == 4001) {  // split-K of under-filled 128-tile launches off / on (A/B measurements)
-    g_split_k = tile - 4000;
-    return MJV_OK;
-  }
-  if (tile >= 2000 && tile < 2100) {  // 2000 + gm: group-M of the tile order (tuning experiments)
-    g_gm = tile - 2000;   // 2000: back to the per-shape choice
-    return MJV_OK;
-  }
-  if (tile >= 1000 && tile < 1010) {  // 1000 + v: keep the automatic tile choice, switch the 256-kernel variant
-    g_variant = tile - 1000;
-    g_force_tile = 0;
-    return MJV_OK;
-  }
-  if (tile != 0 && tile != 64 && tile != 128 && tile != 256) {
-    mjv_set_error("gemm_set_tile: %d not in {0,64,128,256}", tile);
-    return MJV_E_ARG;
-  }
-  g_force_tile = tile;
-  if (tile == 0) g_variant = 0;   // "automatic" also leaves the experimental kernel variants
-  return MJV_OK;
+#ifdef MJV_BENCH
+// measurement switches of the bench library (include/mjv_bench.h); process-wide, never part of the product build
+extern "C" int mjv_bench_gemm_set(int32_t code) {
+  if (code > 4100 && code <= 4108) { g_tune.split_max = code - 4100; return MJV_OK; }
+  if (code >= 6000 && code <= 6512) { g_tune.skinny_max_m = code - 6000; return MJV_OK; }   // 6000 switches the skinny kernel off
+  if (code > 4300 && code <= 4364) { g_tune.split256_min_kt = code - 4300; return MJV_OK; }
+  if (code == 4200 || code == 4201) { g_tune.split256 = code - 4200; return MJV_OK; }
+  if (code == 4000 || code == 4001) { g_tune.split_k = code - 4000; return MJV_OK; }
+  if (code >= 2000 && code < 2100) { g_tune.gm = code - 2000; return MJV_OK; }               // 2000: back to the per-shape choice
+  if (code >= 1000 && code < 1010) { g_tune.variant = code - 1000; return MJV_OK; }           // 1000: production kernel
+  if (code == 0) { g_tune = GemmTune{}; return MJV_OK; }
+  mjv_set_error("bench_gemm_set: unknown code %d", code);
+  return MJV_E_ARG;
 }
-
 // diagnostic (variant 1006): 8 x uint64 per workgroup of the following 256-tile launches go to this device buffer
-extern "C" int mjv_gemm_stamp_buffer(void* p) {
-  g_stamp_buffer = p;
+extern "C" int mjv_bench_gemm_stamp_buffer(void* p) {
+  g_tune.stamp_buffer = p;
   return MJV_OK;
 }
+#endif
 
 extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   MJV_REQUIRE(d && d->A && d->W && d->C, "gemm: null pointer");
   MJV_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+  MJV_REQUIRE(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256, "gemm: tile %d not in {0, 64, 128, 256}", d->tile);
+  const int force_tile = d->tile;
   MJV_REQUIRE(d->K % 64 == 0, "gemm: K=%d must be a multiple of 64", d->K);
   MJV_REQUIRE(d->N % 8 == 0, "gemm: N=%d must be a multiple of 8", d->N);
   MJV_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldc % 4 == 0, "gemm: leading dims must be multiples of 8");
@@ -1166,11 +1161,11 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.m_base = 0;
   a.ws = nullptr;
   a.split = 1;
-  a.gm = g_gm > 0 ? g_gm : pick_gm(d->N, d->K);
+  a.gm = MJV_TUNE(gm) > 0 ? MJV_TUNE(gm) : pick_gm(d->N, d->K);
   a.rope_cos = d->rope_cos; a.rope_sin = d->rope_sin; a.rope_pos = d->rope_pos; a.rope_q = d->rope_q; a.rope_k = d->rope_k;
   a.rope_ldq = d->rope_ldq; a.rope_ldk = d->rope_ldk; a.rope_group = d->rope_group;
   a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;
-  const bool big = g_force_tile ? g_force_tile == 256 : (d->M >= 512 && d->N >= 256);
+  const bool big = force_tile ? force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;
   g_num_cus = mjv_device_cus();   // tail peeling and split-K plan against the CUs of THIS device (partitioned parts differ)
   const double flops = 2.0 * d->M * (double)d->N * d->K;
@@ -1180,7 +1175,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   // round is under-filled, the trailing m-tile rows are peeled off and run as 128x128 tiles (2 workgroups per CU,
   // quarter-size work items) in a second launch on the same stream; rows are independent, so results are unchanged.
   int m_main = d->M;
-  if (big && !g_force_tile && !d->out_rows) {
+  if (big && !force_tile && !d->out_rows) {
     const int tn = (d->N + 255) / 256, tmx = (d->M + 255) / 256;
     const int tiles = tn * tmx;
     const int rem = tiles % g_num_cus;
@@ -1206,13 +1201,13 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   // divided by the CUs it occupies.  Splitting K over more workgroups engages the idle CUs; the slices' fp32
   // accumulators go through the caller's workspace and a second, fully parallel launch sums them in slice order.
   auto plan_split = [&](GemmArgs& g) {
-    if (!g_split_k || !d->workspace) return;
+    if (!MJV_TUNE(split_k) || !d->workspace) return;
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128), nk = g.K / 64;
     // measured (tools/gemm_bench.py, MJV_BENCH_TAILS=1): the second launch costs about 5 us, so K = 1024 / 2048 tails lose
     // 1-5 us while K = 4096 / 8192 tails gain 12 / 25 us (45 -> 33, 89 -> 64)
     if (tiles >= 2 * g_num_cus || nk < 64) return;
     int sp = (2 * g_num_cus) / tiles;
-    if (sp > g_split_max) sp = g_split_max;
+    if (sp > MJV_TUNE(split_max)) sp = MJV_TUNE(split_max);
     if (sp > nk / 4) sp = nk / 4;
     if (sp < 2 || (long)tiles * sp * 65536L > d->workspace_bytes) return;
     g.split = sp;
@@ -1226,14 +1221,14 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   // (tools/gemm_bench.py, MJV_BENCH_TAILS=1: 1104 x 2048 x 8192 in 56 us against 64 us on sliced 128 tiles and 141 us on
   // unsliced 256 tiles; 2186 rows: 83 against 145 us).  At K = 2048 it is a wash or a loss (wqkv tail 41 -> 44 us): not used.
   auto plan_split256 = [&](GemmArgs& g) -> bool {
-    if (!g_split256 || g_force_tile || !d->workspace || d->out_rows) return false;
+    if (!MJV_TUNE(split256) || force_tile || !d->workspace || d->out_rows) return false;
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), nk = g.K / 64;
     // (a last m-tile that is mostly empty wastes its share of every slice: 138 rows x 16384 columns ran 10 % slower sliced)
     const bool filled = (long)g.M * 10 >= (long)((g.M + 255) / 256) * 256 * 7;
-    if (g.M <= g_skinny_max_m || g.N < 256 || nk < 64 || tiles * 2 > g_num_cus || !filled) return false;
+    if (g.M <= MJV_TUNE(skinny_max_m) || g.N < 256 || nk < 64 || tiles * 2 > g_num_cus || !filled) return false;
     int sp = g_num_cus / tiles;
-    if (sp > g_split_max) sp = g_split_max;
-    if (sp > nk / g_split256_min_kt) sp = nk / g_split256_min_kt;
+    if (sp > MJV_TUNE(split_max)) sp = MJV_TUNE(split_max);
+    if (sp > nk / MJV_TUNE(split256_min_kt)) sp = nk / MJV_TUNE(split256_min_kt);
     if (sp < 2 || (long)tiles * sp * 262144L > d->workspace_bytes) return false;
     g.split = sp;
     g.ws = (float*)d->workspace;
@@ -1242,7 +1237,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   auto run = [&](GemmArgs g, bool use_big) -> int {
     if (plan_split256(g)) use_big = true;
     // skinny problems (peeled tails of a few dozen rows, batch-sized head layers): the 64 x 32 kernel
-    const bool skinny = !use_big && (g_force_tile ? g_force_tile == 64 : g.M <= g_skinny_max_m);
+    const bool skinny = !use_big && (force_tile ? force_tile == 64 : g.M <= MJV_TUNE(skinny_max_m));
     if (!use_big && !skinny) plan_split(g);
     const double frac = (double)g.M / (double)d->M;
     // the rotary epilogue needs a whole 256-column tile staged in LDS: only the unsplit 256^2 kernel has it.  Rows that run

@@ -294,10 +294,14 @@ class GatingNetwork(nn.Module):
 
 # ------------------------------------------------------------------------------------ the reward model
 class InternVLChatRewardModeling(nn.Module):
-    def __init__(self, name: str, config, base_model: Optional[InternVLChatModel] = None):
+    def __init__(self, name: str, config, base_model: Optional[InternVLChatModel] = None, allow_uninitialized: bool = False):
+        """``allow_uninitialized``: build the base model's skeleton even if ``name`` holds no ``*.safetensors`` - for callers
+        that load a FULL checkpoint right after (``load_state_dict(strict=True)`` then leaves no parameter uninitialised:
+        scripts/eval/eval_genai_mjvideo.py with ``--checkpoint_path``); the default refuses, like ``from_pretrained``."""
         super().__init__()
         self.num_labels = getattr(config, "num_labels", 2)
-        self.model = base_model if base_model is not None else InternVLChatModel.from_pretrained(name, config=config)
+        self.model = base_model if base_model is not None else InternVLChatModel.from_pretrained(
+            name, config=config, allow_uninitialized=allow_uninitialized)
         config_dict = config.to_dict()
         self.num_objectives = config_dict["num_objectives"]
         self.num_aspects = config_dict["num_aspects"]
@@ -329,6 +333,7 @@ class InternVLChatRewardModeling(nn.Module):
         self._ws_tag = "g0"
         self._host_cache = None
         self.debug_probes: Optional[Dict[str, torch.Tensor]] = None  # tests set {} to capture per-layer states
+        self.use_gemm_workspace = True   # hand the GEMMs of a forward a split-K scratch (False: no GEMM slices K; tests)
 
     # -- construction helpers -------------------------------------------------------------------
     @classmethod
@@ -621,8 +626,10 @@ class InternVLChatRewardModeling(nn.Module):
         """Scores the batch on the CURRENT stream of the model's device (outputs go to rows [lo, lo+B) of ``outs``)."""
         dev = pixel_values.device
         self._ws_tag = tag
-        # split-K scratch of this forward's GEMMs (private to the stream the forward runs on)
-        ops.set_gemm_workspace(self._buf("gemm_ws", 1, ops.gemm_workspace_bytes(), dev, dtype=torch.uint8))
+        # split-K scratch of this forward's GEMMs (private to this model instance and to the stream the forward runs on;
+        # ops keeps it per THREAD: another thread scoring with another model instance has its own)
+        ops.set_gemm_workspace(self._buf("gemm_ws", 1, ops.gemm_workspace_bytes(), dev, dtype=torch.uint8)
+                               if self.use_gemm_workspace else None)
         info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])  # host arrays (see forward)
         B, total = info["B"], info["total"]
         lc = self.config.llm_config
@@ -761,7 +768,7 @@ class InternVLChatRewardModeling(nn.Module):
             # per-device kernel attributes), whatever the caller's current device is: model.cuda(1) works like the reference
             with torch.cuda.device(dev):
                 self._forward_group(d, "g0", pixel_values, ids_h, am_h, outs, 0, True)
-        finally:   # the split-K scratch is a process-wide setting of ops: do not leave it behind for other gemm callers
+        finally:   # the split-K scratch is this thread's default in ops: do not leave it behind for other gemm callers
             ops.set_gemm_workspace(None)
         self.last_packed34 = outs.pop("packed34")
         return CustomOutput(**outs)

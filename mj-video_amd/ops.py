@@ -1,10 +1,13 @@
 """Thin tensor-level wrappers over the C ABI: torch supplies device memory and the current HIP stream,
 every computation happens in libmjv_hip.so.  Every function enqueues on the current HIP stream OF THE DEVICE ITS
-TENSORS LIVE ON (``torch.cuda.current_stream(t.device)``), never on the process-wide current device's stream.
+TENSORS LIVE ON (``torch.cuda.current_stream(t.device)``) and makes that device the current one for the call (the
+library reads the current device for its CU count and per-device kernel attributes), so a direct ``ops.*`` call on
+cuda:1 tensors works whatever the caller's current device is.
 """
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
@@ -37,7 +40,16 @@ def _row_stride(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
-_GEMM_WS: Optional[torch.Tensor] = None
+class _CallDefaults(threading.local):
+    """Per-THREAD defaults of the per-call choices the C ABI takes in its descriptors (ABI 4 has no process-wide setter):
+    the split-K scratch of this thread's GEMM calls, the forced tile kernel and the attention kernel (parity tests).  Two
+    threads scoring on two streams each see their own."""
+    gemm_ws: Optional[torch.Tensor] = None
+    tile: int = 0
+    attn_kernel: int = 0
+
+
+_tls = _CallDefaults()
 
 
 def gemm_workspace_bytes() -> int:
@@ -45,21 +57,22 @@ def gemm_workspace_bytes() -> int:
 
 
 def set_gemm_workspace(ws: Optional[torch.Tensor]) -> None:
-    """Scratch buffer handed to every following ``gemm`` call issued from this thread's launches (uint8/any dtype, on the
-    GPU, private to the stream the calls go to while they are in flight).  None: GEMMs never split K."""
-    global _GEMM_WS
+    """Scratch buffer handed to every following ``gemm`` call of THIS THREAD that does not pass its own ``workspace``
+    (uint8/any dtype, on the GPU, private to the stream the calls go to while they are in flight).  None: never split K."""
     if ws is not None:
         assert ws.is_cuda and ws.is_contiguous() and ws.data_ptr() % 16 == 0
-    _GEMM_WS = ws
+    _tls.gemm_ws = ws
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_BIAS,
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, res_mod: int = 0, res_off: int = 0, out_group: int = 0,
          out_pad: int = 0, out_rows: Optional[torch.Tensor] = None, M: Optional[int] = None,
-         rope: Optional[tuple] = None) -> torch.Tensor:
+         rope: Optional[tuple] = None, workspace: Optional[torch.Tensor] = None, tile: Optional[int] = None) -> torch.Tensor:
     """out = epilogue(a[M,K] @ w[N,K]^T); 2-D row-contiguous bf16 views (row strides are honoured).
-    ``rope`` (EPI_ROPE_QKV only) = (cos, sin, positions, q_out, k_out, group): see include/mjv.h."""
+    ``rope`` (EPI_ROPE_QKV only) = (cos, sin, positions, q_out, k_out, group): see include/mjv.h.
+    ``workspace``: split-K scratch of THIS call (default: the calling thread's ``set_gemm_workspace`` buffer);
+    ``tile``: 0 automatic, 64 / 128 / 256 force one tile kernel (default: the calling thread's ``gemm_set_tile`` value)."""
     _chk_bf16(a, w, out, bias, scale, res)
     lib = load_library()
     d = GemmDesc()
@@ -84,22 +97,38 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         d.rope_cos, d.rope_sin, d.rope_pos = cos.data_ptr(), sin.data_ptr(), positions.data_ptr()
         d.rope_q, d.rope_k = q_out.data_ptr(), k_out.data_ptr()
         d.rope_ldq, d.rope_ldk, d.rope_group = _row_stride(q_out), _row_stride(k_out), group
-    if _GEMM_WS is not None and _GEMM_WS.device == a.device:
-        d.workspace, d.workspace_bytes = _GEMM_WS.data_ptr(), _GEMM_WS.numel() * _GEMM_WS.element_size()
-    check(lib.mjv_gemm_bf16(C.byref(d), _stream(out)), "mjv_gemm_bf16")
+    ws = workspace if workspace is not None else _tls.gemm_ws
+    if ws is not None and ws.device == a.device:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    d.tile = _tls.tile if tile is None else tile
+    with torch.cuda.device(out.device):   # the library plans against / sets attributes on the CURRENT device
+        check(lib.mjv_gemm_bf16(C.byref(d), _stream(out)), "mjv_gemm_bf16")
     return out
 
 
 def gemm_set_tile(tile: int) -> None:
-    """0 = automatic choice, 128 / 256 = force that tile kernel (parity tests)."""
-    check(load_library().mjv_gemm_set_tile(tile), "mjv_gemm_set_tile")
+    """This THREAD's default tile kernel: 0 = automatic choice, 64 / 128 / 256 = force that kernel (parity tests).  Codes
+    >= 1000 are the measurement switches of the bench build (include/mjv_bench.h; process-wide) and need that library
+    (MJV_LIBRARY=.../libmjv_hip_bench.so)."""
+    if tile in (0, 64, 128, 256):
+        _tls.tile = tile
+        if tile == 0 and hasattr(load_library(), "mjv_bench_gemm_set") and getattr(load_library().mjv_bench_gemm_set, "argtypes", None):
+            check(load_library().mjv_bench_gemm_set(1000), "mjv_bench_gemm_set")   # "automatic" also leaves the kernel variants
+        return
+    lib = load_library()
+    if getattr(getattr(lib, "mjv_bench_gemm_set", None), "argtypes", None) is None:
+        raise _lib.MjvLibraryError(f"gemm_set_tile({tile}): measurement switches exist in the bench build only "
+                                   "(make -C mj-video_amd/csrc bench; MJV_LIBRARY=<repo>/mj-video_amd/libmjv_hip_bench.so)")
+    check(lib.mjv_bench_gemm_set(tile), "mjv_bench_gemm_set")
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, cu_seqlens: torch.Tensor,
               max_seqlen: int, n_heads: int, kv_group: int, head_dim: int, causal: bool, scale: float,
               score_round_mode: int, q_head_stride: Optional[int] = None, k_head_stride: Optional[int] = None,
-              v_head_stride: Optional[int] = None, o_head_stride: Optional[int] = None) -> torch.Tensor:
-    """q/k/v/out are 2-D views [rows, >= heads*head_dim] (row stride honoured, first head at column 0)."""
+              v_head_stride: Optional[int] = None, o_head_stride: Optional[int] = None,
+              kernel: Optional[int] = None) -> torch.Tensor:
+    """q/k/v/out are 2-D views [rows, >= heads*head_dim] (row stride honoured, first head at column 0).
+    ``kernel``: 0 automatic, 4 / 5 = the round-1 / round-2 kernels (default: the calling thread's ``attention_set_variant``)."""
     _chk_bf16(q, k, v, out)
     assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_cuda
     lib = load_library()
@@ -114,12 +143,26 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     d.n_seqs, d.max_seqlen = cu_seqlens.numel() - 1, max_seqlen
     d.n_heads, d.kv_group, d.head_dim = n_heads, kv_group, head_dim
     d.causal, d.scale, d.score_round_mode = int(causal), scale, score_round_mode
-    check(lib.mjv_attention_bf16(C.byref(d), _stream(out)), "mjv_attention_bf16")
+    d.kernel = _tls.attn_kernel if kernel is None else kernel
+    with torch.cuda.device(out.device):
+        check(lib.mjv_attention_bf16(C.byref(d), _stream(out)), "mjv_attention_bf16")
     return out
 
 
 def attention_set_variant(v: int) -> None:
-    check(load_library().mjv_attention_set_variant(v), "mjv_attention_set_variant")
+    """This THREAD's default attention kernel: 0 automatic, 4 = register-staged round-1 kernel, 5 = round-2 choice (all
+    correct; tests A/B them).  1-3 and 6 are measurement variants of the bench build (process-wide, bench library only)."""
+    lib = load_library()
+    bench = getattr(getattr(lib, "mjv_bench_attention_set", None), "argtypes", None) is not None
+    if v in (0, 4, 5):
+        _tls.attn_kernel = v
+        if bench:
+            check(lib.mjv_bench_attention_set(0), "mjv_bench_attention_set")
+        return
+    if not bench:
+        raise _lib.MjvLibraryError(f"attention_set_variant({v}): measurement variants exist in the bench build only")
+    _tls.attn_kernel = 5 if v in (1, 2, 3) else 0
+    check(lib.mjv_bench_attention_set(v), "mjv_bench_attention_set")
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float,
@@ -127,9 +170,10 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
     _chk_bf16(x, gamma, beta, out)
     lib = load_library()
     rows = out.shape[0] if rows is None else rows
-    check(lib.mjv_layernorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), gamma.data_ptr(),
-                                 beta.data_ptr(), rows, out.shape[1], eps, gather_grid, _stream(out)),
-          "mjv_layernorm_bf16")
+    with torch.cuda.device(out.device):
+        check(lib.mjv_layernorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), gamma.data_ptr(),
+                                     beta.data_ptr(), rows, out.shape[1], eps, gather_grid, _stream(out)),
+              "mjv_layernorm_bf16")
     return out
 
 
@@ -139,8 +183,9 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, eps: float,
     lib = load_library()
     if row_index is not None:
         assert row_index.dtype == torch.int32 and row_index.is_cuda
-    check(lib.mjv_rmsnorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), w.data_ptr(),
-                               _p(row_index), out.shape[0], out.shape[1], eps, _stream(out)), "mjv_rmsnorm_bf16")
+    with torch.cuda.device(out.device):
+        check(lib.mjv_rmsnorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), w.data_ptr(),
+                                   _p(row_index), out.shape[0], out.shape[1], eps, _stream(out)), "mjv_rmsnorm_bf16")
     return out
 
 
@@ -150,40 +195,45 @@ def rope_split(qkv: torch.Tensor, q: torch.Tensor, k: torch.Tensor, cos: torch.T
     assert positions.dtype == torch.int32 and positions.is_cuda
     assert cos.shape[1] == 128 and cos.is_contiguous() and sin.is_contiguous()
     lib = load_library()
-    check(lib.mjv_rope_split_bf16(qkv.data_ptr(), _row_stride(qkv), q.data_ptr(), _row_stride(q), k.data_ptr(),
-                                  _row_stride(k), cos.data_ptr(), sin.data_ptr(), positions.data_ptr(),
-                                  qkv.shape[0], kv_heads, group, _stream(qkv)), "mjv_rope_split_bf16")
+    with torch.cuda.device(qkv.device):
+        check(lib.mjv_rope_split_bf16(qkv.data_ptr(), _row_stride(qkv), q.data_ptr(), _row_stride(q), k.data_ptr(),
+                                      _row_stride(k), cos.data_ptr(), sin.data_ptr(), positions.data_ptr(),
+                                      qkv.shape[0], kv_heads, group, _stream(qkv)), "mjv_rope_split_bf16")
 
 
 def patchify(pixels: torch.Tensor, patches: torch.Tensor, patch: int) -> torch.Tensor:
     _chk_bf16(pixels, patches)
     assert pixels.is_contiguous() and pixels.dim() == 4 and pixels.shape[1] == 3 and pixels.shape[2] == pixels.shape[3]
     lib = load_library()
-    check(lib.mjv_patchify_bf16(pixels.data_ptr(), patches.data_ptr(), _row_stride(patches), pixels.shape[0],
-                                pixels.shape[2], patch, _stream(patches)), "mjv_patchify_bf16")
+    with torch.cuda.device(patches.device):
+        check(lib.mjv_patchify_bf16(pixels.data_ptr(), patches.data_ptr(), _row_stride(patches), pixels.shape[0],
+                                    pixels.shape[2], patch, _stream(patches)), "mjv_patchify_bf16")
     return patches
 
 
 def cls_rows(x: torch.Tensor, cls: torch.Tensor, pos0: torch.Tensor, tiles: int, tokens_per_tile: int) -> None:
     _chk_bf16(x, cls, pos0)
     lib = load_library()
-    check(lib.mjv_cls_rows_bf16(x.data_ptr(), _row_stride(x), cls.data_ptr(), pos0.data_ptr(), tiles,
-                                tokens_per_tile, x.shape[1], _stream(x)), "mjv_cls_rows_bf16")
+    with torch.cuda.device(x.device):
+        check(lib.mjv_cls_rows_bf16(x.data_ptr(), _row_stride(x), cls.data_ptr(), pos0.data_ptr(), tiles,
+                                    tokens_per_tile, x.shape[1], _stream(x)), "mjv_cls_rows_bf16")
 
 
 def embed_gather(ids: torch.Tensor, table: torch.Tensor, x: torch.Tensor, skip_id: int) -> None:
     _chk_bf16(table, x)
     assert ids.dtype == torch.int32 and ids.is_cuda
     lib = load_library()
-    check(lib.mjv_embed_gather_bf16(ids.data_ptr(), table.data_ptr(), _row_stride(table), x.data_ptr(),
-                                    _row_stride(x), ids.numel(), x.shape[1], skip_id, table.shape[0], _stream(x)),
-          "mjv_embed_gather_bf16")
+    with torch.cuda.device(x.device):
+        check(lib.mjv_embed_gather_bf16(ids.data_ptr(), table.data_ptr(), _row_stride(table), x.data_ptr(),
+                                        _row_stride(x), ids.numel(), x.shape[1], skip_id, table.shape[0], _stream(x)),
+              "mjv_embed_gather_bf16")
 
 
 def reward_heads(desc: HeadsDesc, device: torch.device) -> None:
     """``device``: where the descriptor's pointers live (a descriptor carries no tensor to take the stream from)."""
     stream = torch.cuda.current_stream(device).cuda_stream
-    check(load_library().mjv_reward_heads_bf16(C.byref(desc), stream), "mjv_reward_heads_bf16")
+    with torch.cuda.device(device):
+        check(load_library().mjv_reward_heads_bf16(C.byref(desc), stream), "mjv_reward_heads_bf16")
 
 
 # ------------------------------------------------------------------------------------ profiler access

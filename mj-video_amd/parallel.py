@@ -34,27 +34,39 @@ def score_pairs_dp(score_fn: Callable[[Sequence], torch.Tensor], pairs: Sequence
 
     ``score_fn(local_pairs) -> [len(local_pairs), 2, width]`` runs the model on this rank's shard.  The block width is a
     property of the model (34 for MJ-VIDEO), known to every rank, so the ONLY collective is one ``all_gather_into_tensor``
-    of equal-sized blocks (shards are padded to the largest one).  Works without an initialised process group."""
+    of equal-sized blocks (shards are padded to the largest one, plus one status row per rank so that a rank whose
+    ``score_fn`` misbehaves makes EVERY rank raise after the collective instead of leaving the others blocked in it).
+    Works without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()):
         return score_fn(pairs).float()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(len(pairs), world, rank)
     local = score_fn(pairs[lo:hi]).float() if hi > lo else None
     per = -(-len(pairs) // world)  # all_gather_into_tensor needs equal blocks: pad to the largest shard
+    bad_width = None
     if local is None:
         if device is None:
             raise ValueError("a rank with an empty shard needs `device` to build its (padding) block")
     else:
         device = local.device
-        if local.shape[-1] != width:
-            raise ValueError(f"score_fn returned width {local.shape[-1]}, expected {width} (pass width=...)")
-    block = torch.zeros(per, 2, width, dtype=torch.float32, device=device)
+        if local.dim() != 3 or local.shape[1] != 2 or local.shape[-1] != width:
+            bad_width = tuple(local.shape)   # reported AFTER the collective, on every rank: raising here would leave the
+            local = None                     # other ranks (empty shards included) blocked in the all-gather
+    # one trailing status row per block: [0, 0] = 0 ok / 1 this rank's score_fn returned a block of the wrong shape
+    block = torch.zeros(per + 1, 2, width, dtype=torch.float32, device=device)
     if local is not None:
         block[:hi - lo] = local
-    out = torch.empty(world * per, 2, width, dtype=torch.float32, device=device)
+    if bad_width is not None:
+        block[per, 0, 0] = 1.0
+    out = torch.empty(world * (per + 1), 2, width, dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(out, block, group=group)
+    out = out.view(world, per + 1, 2, width)
+    failed = [r for r in range(world) if float(out[r, per, 0, 0]) != 0.0]
+    if failed:
+        raise ValueError(f"score_fn returned a block of the wrong shape on rank(s) {failed}"
+                         + (f" (here: {bad_width}, expected [pairs, 2, {width}]; pass width=...)" if bad_width is not None else ""))
     rows = []
     for r in range(world):
         a, b = shard_bounds(len(pairs), world, r)
-        rows.append(out[r * per:r * per + (b - a)])
+        rows.append(out[r, :b - a])
     return torch.cat(rows, dim=0)

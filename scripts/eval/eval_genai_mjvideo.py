@@ -52,7 +52,8 @@ def build_model(args, tokenizer, device):
         args.model_name, num_objectives=args.num_objectives, num_aspects=args.num_aspects,
         aspect2criteria=dict(DEFAULT_ASPECT2CRITERIA), gating_temperature=args.gating_temperature,
         gating_hidden_dim=args.gating_hidden_dim, gating_n_hidden=args.gating_n_hidden)
-    model = InternVLChatRewardModeling(args.model_name, config)
+    # with --checkpoint_path the full state dict is loaded strictly below, so a model dir holding only config + tokenizer is enough
+    model = InternVLChatRewardModeling(args.model_name, config, allow_uninitialized=args.checkpoint_path is not None)
     if args.checkpoint_path is not None:
         from safetensors.torch import load_file
         files = sorted(f for f in os.listdir(args.checkpoint_path) if f.endswith(".safetensors"))

@@ -57,3 +57,84 @@ def test_dp_two_ranks_equals_single_process(n_pairs):
         assert torch.equal(out, single), rank          # every rank holds the full block, original order, bitwise
         seen += [x for c in calls for x in c]
     assert sorted(seen) == list(range(100, 100 + n_pairs))  # each pair scored exactly once across ranks
+
+
+def _bench_worker(rank, world, port, pairs_per_rank, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    global_pairs = list(range(world * pairs_per_rank))
+    seen = []
+
+    def score_local(local):          # the model's place: this rank's shard only
+        seen.append(list(local))
+        return fake_scores([1000 + p for p in local])
+
+    out = bench.dp_step(score_local, global_pairs, torch.device("cpu"))
+    q.put((rank, out, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_function_world2():
+    """bench.py's step at N > 1 (dp_step -> parallel.score_pairs_dp: contiguous shards, one all-gather) at world size 2 over
+    gloo: every rank ends with the whole [pairs, 2, 34] block in pair order, each rank scored exactly its own 8 pairs
+    (BASELINE configs[2]'s shard size)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, 8, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = fake_scores([1000 + p for p in range(16)])
+    for rank, out, seen in results:
+        assert torch.equal(out, expect), rank
+        assert seen == [list(range(8 * rank, 8 * rank + 8))]
+
+
+def _bad_width_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def score_fn(local):             # rank 1 misbehaves; with 1 pair rank 1's shard is EMPTY, with 3 it is not
+        return torch.zeros(len(local), 2, 34 if rank == 0 else 33)
+
+    outcome = []
+    for n in (3, 1):
+        try:
+            parallel.score_pairs_dp(score_fn, list(range(n)), device=torch.device("cpu"))
+            outcome.append("ok")
+        except ValueError as e:
+            outcome.append("ValueError")
+    q.put((rank, outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_wrong_width_raises_on_every_rank_after_the_collective():
+    """a rank whose score_fn returns the wrong width must not raise BEFORE the all-gather (the other ranks - an empty-shard
+    rank included - would stay blocked in it): every rank raises after the collective; a rank with an empty shard never
+    calls score_fn, so a 1-pair batch passes"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bad_width_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0] == ["ValueError", "ok"] and results[1] == ["ValueError", "ok"]

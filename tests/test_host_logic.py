@@ -22,9 +22,55 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib = _lib.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mjv_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.mjv_abi_version() == _lib.ABI_VERSION == 4
     assert lib.mjv_arch() == b"gfx950"
     assert os.path.dirname(path).endswith("mj-video_amd")  # in-tree, so the driver sees it loaded
+    # ABI 4: no process-wide setter in the product header, and the product library neither exports the measurement switches
+    # of the bench build (include/mjv_bench.h) nor contains the kernel variants they select
+    assert not [n for n in declared if "_set" in n], [n for n in declared if "_set" in n]
+    bench_header = open(os.path.join(ROOT, "include", "mjv_bench.h")).read()
+    bench_declared = set(re.findall(r"\b(mjv_bench_[a-z0-9_]+)\s*\(", bench_header))
+    assert bench_declared == set(_lib.BENCH_SYMBOLS), bench_declared ^ set(_lib.BENCH_SYMBOLS)
+    raw = ctypes.CDLL(path)
+    for name in bench_declared:
+        assert not hasattr(raw, name), f"{name} exported by the product library"
+
+
+def test_per_call_choices_are_validated_and_thread_local():
+    import threading
+    from mj_video_amd import ops
+    lib = _lib.load_library()
+    d = _lib.GemmDesc()
+    d.A = d.W = d.C = 1024
+    d.M, d.N, d.K = 4, 8, 64
+    d.lda = d.ldw = 64
+    d.ldc = 8
+    d.tile = 100
+    assert lib.mjv_gemm_bf16(ctypes.byref(d), None) == -1 and b"tile" in lib.mjv_last_error()
+    a = _lib.AttnDesc()
+    a.Q = a.K = a.V = a.O = a.cu_seqlens = 1024
+    a.head_dim, a.kernel = 64, 3
+    assert lib.mjv_attention_bf16(ctypes.byref(a), None) == -1 and b"kernel" in lib.mjv_last_error()
+    # the Python-side defaults are per thread
+    ops.gemm_set_tile(128)
+    ops.attention_set_variant(5)
+    seen = {}
+
+    def other():
+        seen["tile"], seen["kernel"], seen["ws"] = ops._tls.tile, ops._tls.attn_kernel, ops._tls.gemm_ws
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    try:
+        assert seen == {"tile": 0, "kernel": 0, "ws": None} and ops._tls.tile == 128 and ops._tls.attn_kernel == 5
+        with pytest.raises(_lib.MjvLibraryError, match="bench build"):
+            ops.gemm_set_tile(1003)          # measurement switches do not exist in the product library
+        with pytest.raises(_lib.MjvLibraryError, match="bench build"):
+            ops.attention_set_variant(2)
+    finally:
+        ops.gemm_set_tile(0)
+        ops.attention_set_variant(0)
 
 
 def test_library_rejects_bad_arguments_without_a_gpu():

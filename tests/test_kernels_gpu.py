@@ -373,16 +373,13 @@ def test_gemm_split_k_matches_unsplit(cuda, M, N, K, epi):
             outs.append(out.clone())
             touched = bool(torch.isfinite(ws[:65536].view(torch.float32)).all())
             assert touched == use_ws, "split-K path taken when it should not be (or not taken when it should)"
-        ops.gemm_set_tile(4000)   # split-K switched off in the library: the workspace must be ignored
-        ws.fill_(255)
-        out = torch.full((M, nout), 7.0, dtype=BF, device=cuda)
-        ops.gemm(a, w, out, **kw)
-        outs.append(out.clone())
-        assert not bool(torch.isfinite(ws[:65536].view(torch.float32)).any())
     finally:
-        ops.gemm_set_tile(4001)
         ops.gemm_set_tile(0)
         ops.set_gemm_workspace(None)
+    # the scratch can also travel in the call itself (thread-safe form): same result
+    out = torch.full((M, nout), 7.0, dtype=BF, device=cuda)
+    ops.gemm(a, w, out, workspace=ws, tile=128, **kw)
+    outs.append(out.clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     lin = a.float() @ w.float().t()
     if epi == "bias":
@@ -437,20 +434,13 @@ def test_gemm_split_k_on_256_tiles(cuda, M, N, K, epi):
     nout = N // 2 if epi == "silu" else N
     ws = torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=cuda)
     outs = []
-    try:
-        ops.set_gemm_workspace(ws)
-        for code in (4201, 4200):          # sliced 256 tiles on / off (off: the 128-tile kernels, as before)
-            ops.gemm_set_tile(code)
-            ws.fill_(255)
-            out = torch.full((M, nout), 7.0, dtype=BF, device=cuda)
-            ops.gemm(a, w, out, **kw)
-            outs.append(out.clone())
-            if code == 4201:               # a whole 256 x 256 fp32 slice image is finite only if the sliced path wrote it
-                assert bool(torch.isfinite(ws[:262144].view(torch.float32)).all()), "256-tile split-K path not taken"
-    finally:
-        ops.gemm_set_tile(4201)
-        ops.gemm_set_tile(0)
-        ops.set_gemm_workspace(None)
+    for tile in (0, 128):                  # automatic choice (K-sliced 256 tiles) / the 128-tile kernels with their own split-K
+        ws.fill_(255)
+        out = torch.full((M, nout), 7.0, dtype=BF, device=cuda)
+        ops.gemm(a, w, out, workspace=ws, tile=tile, **kw)
+        outs.append(out.clone())
+        if tile == 0:                      # a whole 256 x 256 fp32 slice image is finite only if the sliced path wrote it
+            assert bool(torch.isfinite(ws[:262144].view(torch.float32)).all()), "256-tile split-K path not taken"
     assert torch.equal(outs[0], outs[1])
     lin = a.float() @ w.float().t()
     if epi == "bias":

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Attention micro-benchmark at the model's two shapes (HIP events, random data)."""
 import sys, os
+os.environ.setdefault("MJV_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mj-video_amd", "libmjv_hip_bench.so"))   # bench build: make -C mj-video_amd/csrc bench
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mj_video_amd import ops

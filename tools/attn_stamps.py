@@ -9,10 +9,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-from mj_video_amd import _lib  # noqa: E402
-
-_lib.LIB_PATH = os.path.join(ROOT, "mj-video_amd", "libmjv_hip_stamps.so")
-from mj_video_amd import ops  # noqa: E402
+os.environ["MJV_LIBRARY"] = os.path.join(ROOT, "mj-video_amd", "libmjv_hip_stamps.so")   # make -C mj-video_amd/csrc stamps
+from mj_video_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load_library()
 lib.mjv_attention_stamp_buffer.restype = C.c_int

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Prints |hip - ref| of every video of the full_c2 fixture with split-K on / off (diagnostic for the tolerance margin)."""
 import sys, os
+os.environ.setdefault("MJV_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mj-video_amd", "libmjv_hip_bench.so"))   # bench build: make -C mj-video_amd/csrc bench
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GEMM micro-benchmark on the GPU box: TFLOP/s per shape / epilogue / tile kernel (HIP events, random data)."""
 import sys, os
+os.environ.setdefault("MJV_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mj-video_amd", "libmjv_hip_bench.so"))   # bench build: make -C mj-video_amd/csrc bench
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -3,6 +3,7 @@
 workgroup): prologue (first LDS fills) / main loop / epilogue pass A (registers -> LDS tile) / pass B (LDS -> HBM), and how
 much of the launch's span the CUs spend between workgroups."""
 import os
+os.environ.setdefault("MJV_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mj-video_amd", "libmjv_hip_bench.so"))   # bench build: make -C mj-video_amd/csrc bench
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,10 +37,10 @@ for name, M, N, K, epi in shapes:
     torch.cuda.synchronize()
     plain_ms = e0.elapsed_time(e1)
     ops.gemm_set_tile(1006)
-    lib.mjv_gemm_stamp_buffer(buf.data_ptr())
+    lib.mjv_bench_gemm_stamp_buffer(buf.data_ptr())
     ops.gemm(a, w, out, epi, bias=bias, scale=scale, res=res)
     torch.cuda.synchronize()
-    lib.mjv_gemm_stamp_buffer(None)
+    lib.mjv_bench_gemm_stamp_buffer(None)
     ops.gemm_set_tile(0)
     d = buf.cpu().double()
     span = (d[:, 0] + d[:, 5]).max().item() - d[:, 0].min().item()

@@ -2,6 +2,7 @@
 """Exactness screen for an experimental 256-tile kernel variant (tile code 1000 + v): exact-integer problems of the model's
 shapes, repeated; every run must equal the production kernel's result bit for bit.  usage: var_check.py <v> [repeats]"""
 import os, sys
+os.environ.setdefault("MJV_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mj-video_amd", "libmjv_hip_bench.so"))   # bench build: make -C mj-video_amd/csrc bench
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
