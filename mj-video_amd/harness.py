@@ -11,6 +11,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Iterable, List, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from .chat_input import prepare_chat_input, video_prefix
@@ -156,3 +157,98 @@ def preference_targets(labels):
     pref = [0 if v == "Video 1 better" else 1 for v in values]
     mask = [1 if v in ("Video 1 better", "Video 2 better") else 0 for v in values]
     return pref, mask
+
+
+# ------------------------------------------------------------------------------------ MJ-BENCH-VIDEO (datas/test.json)
+ASPECT_KEYS = ("Alignment", "Safety", "Fineness", "Consistency", "Bias")   # order of video_*_overall_score in test.json
+
+
+@dataclass
+class ConfusionCounts:
+    """Per-dimension bookkeeping of scripts/train/overall_train.py:308-324 (``calculate_metrics``): predictions are the signs
+    of the model's outputs (``> 0``), a label counts as positive when it EQUALS 1 and as negative when it EQUALS 0 (the
+    dataset's default labels use -1 for "bad", dataset.py:52-85, which is neither - the reference's own quirk, reproduced),
+    and only dimensions with a non-zero relevance mask are counted."""
+    dims: int
+    correct: np.ndarray = None
+    total: np.ndarray = None
+    tp: np.ndarray = None
+    fp: np.ndarray = None
+    tn: np.ndarray = None
+    fn: np.ndarray = None
+
+    def __post_init__(self):
+        for f in ("correct", "total", "tp", "fp", "tn", "fn"):
+            setattr(self, f, np.zeros(self.dims, dtype=np.float64))
+
+    def update(self, predictions, ground_truth, mask) -> None:
+        pred = np.asarray(predictions, dtype=bool).ravel()
+        gt = np.asarray(ground_truth).ravel()
+        active = np.asarray(mask).ravel() != 0
+        self.correct += (pred.astype(gt.dtype) == gt) & active
+        self.tp += pred & (gt == 1) & active
+        self.fp += pred & (gt == 0) & active
+        self.tn += ~pred & (gt == 0) & active
+        self.fn += ~pred & (gt == 1) & active
+        self.total += active
+
+    def summary(self) -> dict:
+        """The figures ``save_metrics`` reports (overall_train.py:326-388): pooled accuracy / precision / recall / F1 and the
+        per-dimension vectors (a dimension that never occurs divides 0 by 0: NaN, as in the reference's tensors)."""
+        def ratio(a, b):
+            return float(a) / float(b) if b > 0 else 0
+        tp, fp, tn, fn = self.tp, self.fp, self.tn, self.fn
+        acc = ratio(self.correct.sum(), self.total.sum())
+        rec = ratio(tp.sum(), (tp + fn).sum())
+        pre = ratio(tp.sum(), (tp + fp).sum())
+        f1 = 2 * (rec * pre) / (rec + pre) if (rec + pre) > 0 else 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            acc_d, rec_d, pre_d = self.correct / self.total, tp / (tp + fn), tp / (tp + fp)
+            f1_d = 2 * (rec_d * pre_d) / (rec_d + pre_d)
+        return dict(accuracy=acc, precision=pre, recall=rec, f1=f1, accuracy_dim=acc_d.tolist(), precision_dim=pre_d.tolist(),
+                    recall_dim=rec_d.tolist(), f1_dim=f1_d.tolist(), tp=tp.tolist(), fp=fp.tolist(), tn=tn.tolist(), fn=fn.tolist())
+
+
+def mjbench_targets(item: dict, mse: bool = True) -> dict:
+    """Label tensors of one datas/test.json pair exactly as VideoDataset builds them (dataset.py:329-398): per video the
+    criteria / aspect scores and relevance masks, plus the overall preference (0 = video 1 better, 1 = video 2 better) and
+    its mask.  The two videos must carry the same label names (dataset.py:346,352)."""
+    out = {}
+    names = None
+    for v in (0, 1):
+        cs, cr, cn = criteria_targets(item[f"video_{v}_label"], mse=mse)
+        a_s, a_r, an = criteria_targets(item[f"video_{v}_overall_score"], mse=mse)
+        if names is not None and names != (cn, an):
+            raise ValueError("the two videos of a pair carry different label names")
+        names = (cn, an)
+        out[f"video_{v}"] = dict(criteria_score=cs, criteria_related=cr, aspect_score=a_s, aspect_related=a_r)
+    pref, mask = preference_targets(item["overall_preference"])
+    out["overall_preference"], out["overall_mask"] = pref[0], mask[0]
+    out["criteria_names"], out["aspect_names"] = names
+    return out
+
+
+def evaluate_mjbench(items: Sequence[dict], scores: "np.ndarray", mse: bool = True) -> dict:
+    """MJ-BENCH-VIDEO evaluation of ``scores`` [pairs, 2, 1 + n_aspects + n_criteria] (the packed block of
+    ``CustomOutput``: score, aspect_scores, rewards per video - what ``parallel.score_pairs_dp`` gathers) against the
+    labels of ``items``: the overall preference accuracy of ``CustomTrainer.evaluate`` (overall_train.py:390-442:
+    prefer_predict = not (score_0 > score_1), counted where the pair has a decisive overall preference) and the aspect /
+    criteria sign metrics of ``evaluate_aspect`` (overall_train.py:204-306)."""
+    scores = np.asarray(scores, dtype=np.float64)
+    n_asp = len(items[0]["video_0_overall_score"])
+    n_crit = len(items[0]["video_0_label"])
+    assert scores.shape == (len(items), 2, 1 + n_asp + n_crit), scores.shape
+    aspect, criteria = ConfusionCounts(n_asp), ConfusionCounts(n_crit)
+    correct = count = 0
+    for i, item in enumerate(items):
+        t = mjbench_targets(item, mse=mse)
+        for v in (0, 1):
+            tv = t[f"video_{v}"]
+            aspect.update(scores[i, v, 1:1 + n_asp] > 0, tv["aspect_score"], tv["aspect_related"])
+            criteria.update(scores[i, v, 1 + n_asp:] > 0, tv["criteria_score"], tv["criteria_related"])
+        prefer_predict = int(not (scores[i, 0, 0] > scores[i, 1, 0]))
+        correct += int(prefer_predict == t["overall_preference"]) * t["overall_mask"]
+        count += t["overall_mask"]
+    return dict(overall_accuracy=(correct / count if count > 0 else 0), overall_correct=correct, overall_count=count,
+                aspect=aspect.summary(), criteria=criteria.summary(), aspect_names=list(items[0]["video_0_overall_score"]),
+                criteria_names=list(items[0]["video_0_label"]))

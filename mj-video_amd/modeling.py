@@ -329,6 +329,7 @@ class InternVLChatRewardModeling(nn.Module):
         self._derived_sig = None
         self._ws: Dict[str, torch.Tensor] = {}
         self._rope: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._rope_state = None   # the reference's rotary cache state (see _rope_tables)
         self.last_packed34: Optional[torch.Tensor] = None
         self._ws_tag = "g0"
         self._host_cache = None
@@ -411,19 +412,27 @@ class InternVLChatRewardModeling(nn.Module):
         return table
 
     def _rope_tables(self, seq_len: int, device):
-        """bf16 cos/sin tables of modeling_internlm2.py:147-180,204-229 (fp32 math, cast once)."""
+        """bf16 cos/sin tables of modeling_internlm2.py:147-229 (fp32 math, cast once), INCLUDING the reference's state:
+        its rotary modules cache ``max_seq_len_cached`` positions (``max_position_embeddings`` at construction) and regrow
+        the cache whenever a forward brings a longer (padded) sequence - and the dynamic-NTK variant then also replaces its
+        ``inv_freq`` for good (:204-229), so every LATER forward, short ones included, rotates with the rescaled base.
+        ``seq_len`` is the padded width of ``input_ids`` (``kv_seq_len`` of :367-372), as the reference passes it."""
         lc = self.config.llm_config
         dim = lc.hidden_size // lc.num_attention_heads
         maxpos = lc.max_position_embeddings
-        n = max(maxpos if seq_len <= maxpos else seq_len, 1)
-        key = (n, str(device))
+        rs = lc.rope_scaling
+        st = self._rope_state
+        if st is None:
+            st = self._rope_state = dict(cached=maxpos, base=float(lc.rope_theta))
+        if seq_len > st["cached"]:
+            st["cached"] = seq_len
+            if rs is not None and rs["type"] == "dynamic" and seq_len > maxpos:
+                st["base"] = float(lc.rope_theta) * ((rs["factor"] * seq_len / maxpos) - (rs["factor"] - 1)) ** (dim / (dim - 2))
+        n = max(st["cached"], 1)
+        key = (n, st["base"], str(device))
         if key in self._rope:
             return self._rope[key]
-        base = float(lc.rope_theta)
-        rs = lc.rope_scaling
-        if seq_len > maxpos and rs is not None and rs["type"] == "dynamic":
-            base = base * ((rs["factor"] * seq_len / maxpos) - (rs["factor"] - 1)) ** (dim / (dim - 2))
-        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+        inv_freq = 1.0 / (st["base"] ** (torch.arange(0, dim, 2).float() / dim))
         t = torch.arange(n, dtype=inv_freq.dtype)
         if rs is not None and rs["type"] == "linear":
             t = t / rs["factor"]
@@ -548,15 +557,8 @@ class InternVLChatRewardModeling(nn.Module):
         if cu is None or cu.device != dev:
             cu = torch.arange(0, (tiles + 1) * T, T, dtype=torch.int32, device=dev)
             self._ws[key] = cu
-        scale = (dim // H) ** -0.5
         for li, layer in enumerate(vm.encoder.layers):
-            ops.layernorm(x, layer.norm1.weight, layer.norm1.bias, h, vc.layer_norm_eps)
-            ops.gemm(h, layer.attn.qkv.weight, qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
-            ops.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], h, cu, T, H, 1, 64, False, scale, 0)
-            ops.gemm(h, layer.attn.proj.weight, x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
-            ops.layernorm(x, layer.norm2.weight, layer.norm2.bias, h, vc.layer_norm_eps)
-            ops.gemm(h, layer.mlp.fc1.weight, f, EPI_BIAS_GELU, bias=layer.mlp.fc1.bias)
-            ops.gemm(f, layer.mlp.fc2.weight, x, EPI_SCALE_RES, bias=layer.mlp.fc2.bias, scale=layer.ls2, res=x)
+            self._vit_layer(layer, x, h, qkv, f, cu, T)
             if probes is not None:
                 probes[f"vit_layer{li}"] = x.clone().view(tiles, T, dim)
         mlp1 = self.model.mlp1
@@ -570,8 +572,65 @@ class InternVLChatRewardModeling(nn.Module):
             probes["vit_embeds"] = hidden[img_rows.long()].clone().view(tiles, -1, hidden.shape[1])
         return x
 
+    def _vit_layer(self, layer, x, h, qkv, f, cu, T):
+        """One InternVisionEncoderLayer (modeling_intern_vit.py:283-295) in place on the packed rows ``x`` [tiles * T, dim];
+        ``h`` / ``qkv`` / ``f`` are scratch buffers of [rows, dim] / [rows, 3 dim] / [rows, intermediate]."""
+        vc = self.config.vision_config
+        dim, H = vc.hidden_size, vc.num_attention_heads
+        scale = (dim // H) ** -0.5
+        ops.layernorm(x, layer.norm1.weight, layer.norm1.bias, h, vc.layer_norm_eps)
+        ops.gemm(h, layer.attn.qkv.weight, qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
+        ops.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], h, cu, T, H, 1, 64, False, scale, 0)
+        ops.gemm(h, layer.attn.proj.weight, x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
+        ops.layernorm(x, layer.norm2.weight, layer.norm2.bias, h, vc.layer_norm_eps)
+        ops.gemm(h, layer.mlp.fc1.weight, f, EPI_BIAS_GELU, bias=layer.mlp.fc1.bias)
+        ops.gemm(f, layer.mlp.fc2.weight, x, EPI_SCALE_RES, bias=layer.mlp.fc2.bias, scale=layer.ls2, res=x)
+
+    @torch.no_grad()
+    def run_vit_layer(self, li: int, x: torch.Tensor) -> torch.Tensor:
+        """Test entry (not part of the reference's API): encoder layer ``li`` of the vision tower on given hidden states
+        ``x`` [tiles, tokens, dim] - the same call sequence ``forward`` runs per layer, nothing before or after it."""
+        dev = self.model.device
+        vc = self.config.vision_config
+        tiles, T, dim = x.shape
+        self._prepare(dev)
+        with torch.cuda.device(dev):
+            ops.set_gemm_workspace(self._buf("gemm_ws", 1, ops.gemm_workspace_bytes(), dev, dtype=torch.uint8)
+                                   if self.use_gemm_workspace else None)
+            try:
+                xs = x.to(dev, BF16).reshape(tiles * T, dim).clone()
+                h = torch.empty_like(xs)
+                qkv = torch.empty(tiles * T, 3 * dim, dtype=BF16, device=dev)
+                f = torch.empty(tiles * T, vc.intermediate_size, dtype=BF16, device=dev)
+                cu = torch.arange(0, (tiles + 1) * T, T, dtype=torch.int32, device=dev)
+                self._vit_layer(self.model.vision_model.encoder.layers[li], xs, h, qkv, f, cu, T)
+            finally:
+                ops.set_gemm_workspace(None)
+        return xs.view(tiles, T, dim)
+
+    @torch.no_grad()
+    def run_llm_layer(self, li: int, x: torch.Tensor) -> torch.Tensor:
+        """Test entry: decoder layer ``li`` of the language tower on given hidden states ``x`` [batch, seq, hidden] (every
+        sequence full length, positions 0 .. seq - 1): the call sequence ``forward`` runs for a layer that is not the
+        trimmed last one."""
+        dev = self.model.device
+        d = self._prepare(dev)
+        B, N, hd = x.shape
+        with torch.cuda.device(dev):
+            ops.set_gemm_workspace(self._buf("gemm_ws", 1, ops.gemm_workspace_bytes(), dev, dtype=torch.uint8)
+                                   if self.use_gemm_workspace else None)
+            try:
+                xs = x.to(dev, BF16).reshape(B * N, hd).clone()
+                cu = torch.arange(0, (B + 1) * N, N, dtype=torch.int32, device=dev)
+                pos = torch.arange(N, dtype=torch.int32, device=dev).repeat(B)
+                self._language_tower(d, xs, cu, pos, N, None, padded_len=N, only_layer=li)
+            finally:
+                ops.set_gemm_workspace(None)
+        return xs.view(B, N, hd)
+
     def _language_tower(self, d, x: torch.Tensor, cu: torch.Tensor, positions: torch.Tensor, max_len: int,
-                        sel_rows: Optional[torch.Tensor] = None):
+                        sel_rows: Optional[torch.Tensor] = None, padded_len: Optional[int] = None,
+                        only_layer: Optional[int] = None):
         """24 decoder layers in place on the packed rows ``x``.  With ``sel_rows`` (the 2 rows per sample the heads
         read) the LAST layer runs wo / FFN only on those rows - every other row of its output is never used
         (moe_reward.py:211,229,243) - and the [len(sel_rows), hidden] result is returned instead of ``x``."""
@@ -583,7 +642,7 @@ class InternVLChatRewardModeling(nn.Module):
         hd = 128
         n, hdim = x.shape
         ff = lc.intermediate_size
-        cos, sin = self._rope_tables(max_len, dev)
+        cos, sin = self._rope_tables(max_len if padded_len is None else padded_len, dev)
         hn = self._buf("llm_hn", n, hdim, dev)
         qkv = self._buf("llm_qkv", n, (H + 2 * KV) * hd, dev)
         q = self._buf("llm_q", n, H * hd, dev)
@@ -593,6 +652,8 @@ class InternVLChatRewardModeling(nn.Module):
         v_view = qkv[:, (G + 1) * hd:]
         last = len(lm.layers) - 1
         for li, layer in enumerate(lm.layers):
+            if only_layer is not None and li != only_layer:   # (run_llm_layer: one layer on given rows)
+                continue
             ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
             # wqkv with the rotary embedding + GQA de-interleave in its epilogue: q / k go (rotated) to their own buffers,
             # v stays in its columns of qkv (modeling_internlm2.py:359-381)
@@ -600,7 +661,7 @@ class InternVLChatRewardModeling(nn.Module):
             ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, 1, v_head_stride=(G + 2) * hd)
             if self.debug_probes is not None and li == 0:   # operands / result of the first causal attention (parity tests)
                 self.debug_probes["llm_attn0"] = dict(q=q.clone(), k=k.clone(), v=v_view.clone(), out=hn.clone(), kv_heads=KV)
-            if li == last and sel_rows is not None and self.debug_probes is None:
+            if li == last and sel_rows is not None and self.debug_probes is None and only_layer is None:
                 ns = sel_rows.numel()
                 att_s = self._buf("llm_att_sel", ns, hdim, dev)
                 x_s = self._buf("llm_x_sel", ns, hdim, dev)
@@ -646,7 +707,7 @@ class InternVLChatRewardModeling(nn.Module):
         if self.debug_probes is not None and probes_ok:
             self.debug_probes["llm_embed"] = hidden.clone()
         trimmed = self.debug_probes is None
-        last_x = self._language_tower(d, hidden, cu, positions, info["max_len"], sel_rows if trimmed else None)
+        last_x = self._language_tower(d, hidden, cu, positions, info["max_len"], sel_rows if trimmed else None, padded_len=info["N"])
 
         # final RMSNorm only on the 2 rows per sample the heads read (hidden_states[-1] is post-norm, moe_reward.py:211)
         h_r, h_g = outs["hidden_state"][lo:lo + B], outs["prompt_embedding"][lo:lo + B]

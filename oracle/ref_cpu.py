@@ -123,24 +123,28 @@ def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return w * h.to(dt)
 
 
-def rope_tables(cfg, seq_len: int, dtype) -> tuple:
+def rope_tables(cfg, seq_len: int, dtype, state: dict = None) -> tuple:
     """internvl2/modeling_internlm2.py:147-180,204-229 - fp32 tables cast to the model dtype.
 
     The tables are built at construction for ``max_position_embeddings`` positions and become
-    bf16 buffers under ``model.to(bfloat16)``; the dynamic-NTK rescale only happens when
-    ``seq_len`` exceeds that."""
+    bf16 buffers under ``model.to(bfloat16)``; a forward whose (padded) sequence is longer regrows them, and the
+    dynamic-NTK variant then also replaces its ``inv_freq`` FOR GOOD (:209-221).  ``state`` (a dict the caller keeps
+    between forwards of one model) carries that memory - ``max_seq_len_cached`` and the base in force - so that a sequence
+    of calls reproduces the reference's; without it every call starts from a freshly constructed model."""
     l = cfg.llm_config
     dim = l.hidden_size // l.num_attention_heads
-    base = float(l.rope_theta)
     maxpos = l.max_position_embeddings
-    n = maxpos
     rs = l.rope_scaling
-    if seq_len > maxpos:
-        n = seq_len
-        if rs is not None and rs["type"] == "dynamic":
-            base = base * ((rs["factor"] * seq_len / maxpos) - (rs["factor"] - 1)) ** (dim / (dim - 2))
-    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
-    t = torch.arange(n, dtype=inv_freq.dtype)
+    if state is None:
+        state = {}
+    state.setdefault("cached", maxpos)
+    state.setdefault("base", float(l.rope_theta))
+    if seq_len > state["cached"]:
+        state["cached"] = seq_len
+        if rs is not None and rs["type"] == "dynamic" and seq_len > maxpos:
+            state["base"] = float(l.rope_theta) * ((rs["factor"] * seq_len / maxpos) - (rs["factor"] - 1)) ** (dim / (dim - 2))
+    inv_freq = 1.0 / (state["base"] ** (torch.arange(0, dim, 2).float() / dim))
+    t = torch.arange(state["cached"], dtype=inv_freq.dtype)
     if rs is not None and rs["type"] == "linear":
         t = t / rs["factor"]
     freqs = torch.einsum("i,j->ij", t, inv_freq)
@@ -227,7 +231,7 @@ def find_token_for_gating(lst: Sequence[int]) -> int:
 def reward_forward(sd: Dict[str, torch.Tensor], cfg, pixel_values: torch.Tensor, input_ids: torch.Tensor,
                    attention_mask: Optional[torch.Tensor], img_context_token_id: int,
                    pad_token_id: Optional[int], lm_head: bool = False,
-                   probes: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+                   probes: Optional[dict] = None, rope_state: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """moe_reward.py:183-297 on top of internvl2/modeling_internvl_chat.py:146-226.
 
     ``sd`` is the checkpoint-layout state dict (all tensors of one dtype).  Returns the
@@ -252,7 +256,7 @@ def reward_forward(sd: Dict[str, torch.Tensor], cfg, pixel_values: torch.Tensor,
     if attention_mask is None:
         attention_mask = torch.ones((B, N), dtype=torch.bool)
     mask = causal_padding_mask(attention_mask, x.dtype)
-    cos, sin = rope_tables(cfg, N, x.dtype)
+    cos, sin = rope_tables(cfg, N, x.dtype, rope_state)   # (rope_state: the rotary cache memory of ONE model across forwards)
     for i in range(l.num_hidden_layers):
         x = llm_layer(sd, cfg, i, x, mask, cos, sin)
         if probes is not None:

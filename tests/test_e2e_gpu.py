@@ -13,6 +13,8 @@ fp32 sum moves a score); TOL_FACTOR = 3 because the difference of two noise samp
 maximum over a few fixture cases under-estimates the maximum over all the elements compared.  The statistical statements
 (rms deviation, preference agreement on decisive pairs, rank correlation) are made on the rank sets.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -520,6 +522,80 @@ def test_k_sliced_path_is_no_further_from_fp32(cuda):
         assert d_on <= 1.5 * d_ref and d_off <= 1.5 * d_ref, (f, d_on, d_off, d_ref)
 
 
+@pytest.mark.parametrize("name", ["vit_layer0", "vit_layer23", "llm_layer0", "llm_layer23"])
+def test_single_layer_at_production_shape(cuda, name):
+    """tests/golden/layers.npz: ONE layer at MJ-VIDEO-2B dimensions and the headline sequence lengths, executed by the
+    reference's own InternVisionEncoderLayer.forward (modeling_intern_vit.py:283-295, [2, 1025, 1024]) /
+    InternLM2DecoderLayer.forward (modeling_internlm2.py:621-681, [1, 2186, 2048]) on seed-defined bf16 rows with the
+    synthetic weights of that layer - no compounding over 24 layers, so the bound can be tight: relative L2 of the
+    sampled output rows against the reference's bf16 run <= 2 x the reference's own bf16-vs-fp32 distance for this
+    layer (0.30 % vision, 0.44 % language), and the HIP rows no further from the fp32 run than 2 x that either."""
+    from util import layer_input_rows, layer_tensors
+    from mj_video_amd import synth
+    from mj_video_amd.modeling import InternVLChatRewardModeling
+    npz, meta = load_golden("layers")
+    m = meta["layers"]
+    case = next(c for c in m["cases"] if c["name"] == name)
+    cfg = make_cfg("2b", m["image_size"])
+    full_prefix = (f"model.vision_model.encoder.layers.{case['layer']}." if case["tower"] == "vit"
+                   else f"model.language_model.model.layers.{case['layer']}.")
+    w = layer_tensors(cfg, full_prefix, m["weight_seed"])
+    cfg.vision_config.num_hidden_layers = 1      # a one-layer skeleton per tower: the layer under test sits at index 0
+    cfg.llm_config.num_hidden_layers = 1
+    cfg.llm_config.vocab_size = 128
+    model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16)
+    for prm in model.parameters():
+        prm.data.zero_()
+    mod = model.model.vision_model.encoder.layers[0] if case["tower"] == "vit" else model.model.language_model.model.layers[0]
+    mod.load_state_dict(w, strict=True)
+    model = model.to(torch.bfloat16).to(cuda).eval()
+    x = layer_input_rows(m["input_seed"], case["input_tag"], tuple(case["shape"]))
+    y = (model.run_vit_layer(0, x) if case["tower"] == "vit" else model.run_llm_layer(0, x)).float().cpu()
+    rows = npz[f"{name}/rows"]
+    got = y[:, rows].numpy()
+    ref = bits_to_f32(npz[f"{name}/out"])
+    f32 = npz[f"{name}/fp32"]
+    noise = case["ref_bf16_vs_fp32"]
+    d_ref, d_f32 = rel_l2(got, ref), rel_l2(got, f32)
+    print(f"{name}: HIP vs reference bf16 {d_ref:.5f}, HIP vs reference fp32 {d_f32:.5f}; reference bf16 vs fp32 {noise:.5f}")
+    assert np.isfinite(got).all()
+    assert d_ref <= 2.0 * noise, (name, d_ref, noise)
+    assert d_f32 <= 2.0 * noise, (name, d_f32, noise)
+
+
+def test_sticky_dynamic_ntk_sequence(cuda):
+    """the reference's rotary cache is stateful (modeling_internlm2.py:169-176,204-229): ONE model scored short -> long ->
+    short -> a padded batch with max_position_embeddings (48) below every sequence length and dynamic-NTK scaling; the
+    third call must reproduce the reference's THIRD call (rescaled base still in force), not its first, and the padded
+    batch regrows the cache by its PADDED width.  Bounds: the tiny-dims noise floor of these very calls."""
+    from mj_video_amd import configuration as C, synth
+    npz, meta = load_golden("layers")
+    m = meta["ntk"]
+    cd = C.tiny_config_dict(m["image_size"])
+    cd["llm_config"]["max_position_embeddings"] = m["max_position_embeddings"]
+    cd["llm_config"]["rope_scaling"] = dict(m["rope_scaling"])
+    cfg = C.InternVLChatRewardModelingConfig(**cd, **C.mjvideo_head_kwargs())
+    model = build_hip_model(cfg, synth.synth_state_dict(cfg, seed=m["weight_seed"]), cuda)
+    names = [f"ntk/{c['name']}" for c in m["calls"]]
+    outs = {}
+    for call in m["calls"]:
+        px, ids, mask, _ = case_inputs(cfg, call["videos"], m["pixel_seed"], m["image_size"])
+        out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+        outs[call["name"]] = out
+        for f in FIELDS:
+            got = getattr(out, f).float().cpu().numpy()
+            ref = npz[f"ntk/{call['name']}/{f}"]
+            tol = TOL_FACTOR * noise_floor(npz, names, f) + ATOL_FLOOR
+            assert np.abs(got - ref).max() <= tol, (call["name"], f, float(np.abs(got - ref).max()), tol)
+    # the state is real: the third call is closer to the reference's third call than to its first
+    h3 = outs["short_again"].hidden_state.float().cpu().numpy()
+    d_third = np.abs(h3 - npz["ntk/short_again/hidden_state"]).max()
+    d_first = np.abs(h3 - npz["ntk/short_first/hidden_state"]).max()
+    print(f"third call: max |d| to the reference's third call {d_third:.4f}, to its first call {d_first:.4f}")
+    assert d_third < d_first
+    assert not torch.equal(outs["short_first"].hidden_state, outs["short_again"].hidden_state)
+
+
 def test_two_threads_two_streams_score_bitwise(cuda):
     """ABI 4 keeps no setting between calls (tile / attention kernel / split-K scratch travel in the descriptors; the Python
     wrappers keep their defaults per thread): two threads, each with its own model instance (same weights) and its own HIP
@@ -685,6 +761,52 @@ def test_eval_driver_protocol(cuda):
     assert (counts.prefer_truth, counts.prefer_total, counts.truth, counts.total) == \
         (ref.prefer_truth, ref.prefer_total, ref.truth, ref.total)
     assert counts.total == 5 and counts.prefer_total == 3
+
+
+def test_mjbench_video_driver(cuda):
+    """scripts/eval/eval_mjbench_video.py: pairs in the datas/test.json schema scored in packed batches through
+    prepare_chat_input + device preprocessing give the same [pairs, 2, 34] block as one forward per video (the reference's
+    loop, overall_train.py:407-421), and the metrics are harness.evaluate_mjbench of that block (the bookkeeping itself is
+    held to the reference's own methods on the CPU: tests/test_host_fixtures.py)"""
+    import importlib.util
+    import sys as _sys
+    import numpy as np
+    from util import GOLDEN, ROOT
+    from mj_video_amd import harness, synth, video
+    from mj_video_amd.chat_input import prepare_chat_input, video_prefix
+    from test_host_logic import StubTokenizer
+    _sys.path.insert(0, GOLDEN)
+    import make_mjbench_fixture as gen
+    spec = importlib.util.spec_from_file_location("mjbench_driver", f"{ROOT}/scripts/eval/eval_mjbench_video.py")
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    cfg = make_cfg("tiny", 56)
+    model = build_hip_model(cfg, synth.synth_state_dict(cfg, seed=31, dtype=torch.float32), cuda)
+    assert model.num_aspects == 5 and model.num_objectives == 28
+    tok = StubTokenizer()
+    rng = np.random.default_rng(7)
+    items = gen.synth_items(9, 5)
+    store = {}
+    for it in items:
+        for v in (0, 1):
+            store[os.path.join("/videos", it[f"video_{v}_path"])] = rng.integers(0, 256, size=(2, 90, 120, 3), dtype=np.uint8)
+
+    def loader(path):
+        return video.load_frames_device(torch.from_numpy(store[path]).to(cuda), input_size=56, max_num=1)[0]
+
+    metrics, scores = drv.evaluate_items(model, cfg, tok, items, loader, "/videos", pairs_per_batch=2)
+    for i, it in enumerate(items):
+        for v in (0, 1):
+            pv = loader(os.path.join("/videos", it[f"video_{v}_path"]))
+            ids, mask = prepare_chat_input(cfg, tok, pv, video_prefix(pv.shape[0]) + it["caption"], {}, device=cuda)
+            out = model.forward(pv, ids, mask)
+            one = torch.cat([out.score.float().view(1), out.aspect_scores.float().view(-1), out.rewards.float().view(-1)])
+            assert torch.equal(one, scores[i, v]), (i, v)
+    again = harness.evaluate_mjbench(items, scores.cpu().numpy())
+    assert {k: metrics[k] for k in ("overall_accuracy", "overall_correct", "overall_count")} == \
+        {k: again[k] for k in ("overall_accuracy", "overall_correct", "overall_count")}
+    assert metrics["aspect"]["tp"] == again["aspect"]["tp"] and metrics["criteria"]["fn"] == again["criteria"]["fn"]
+    assert metrics["overall_count"] == sum(it["overall_preference"] in ("Video 1 better", "Video 2 better") for it in items)
 
 
 def _small_backbone_2b_heads(cuda, image_size=224):

@@ -6,6 +6,7 @@ scripts/data_processor/dataset.py:52-112)."""
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -74,3 +75,35 @@ def test_label_targets_match_the_reference():
             assert harness.criteria_targets(rec["labels"], mse=rec["mse"]) == (rec["score"], rec["related"], rec["names"]), rec
     for rec in HOST["deal_preference"]:
         assert harness.preference_targets(rec["labels"]) == (rec["preference"], rec["mask"]), rec
+
+
+def test_mjbench_video_bookkeeping_matches_the_reference():
+    """tests/golden/mjbench.json: numbers the reference's own CustomTrainer.evaluate / evaluate_aspect / calculate_metrics /
+    save_metrics (scripts/train/overall_train.py:204-442, executed by make_mjbench_fixture.py) produced on synthetic
+    datas/test.json-schema labels and synthetic model outputs, both regenerated here from the stored seeds:
+    harness.evaluate_mjbench must give the same overall preference accuracy, the same pooled aspect / criteria accuracy,
+    precision, recall, F1 and the same TP / FP / TN / FN per label dimension (and, at batch size 1, where the reference's
+    "dim" is the label dimension, the same per-dimension metrics, NaN for dimensions that never occur)."""
+    import math
+    sys.path.insert(0, GOLDEN)
+    import make_mjbench_fixture as gen
+    fix = json.load(open(os.path.join(GOLDEN, "mjbench.json")))
+    assert fix["cases"]
+    for case in fix["cases"]:
+        items, scores = gen.synth_items(case["seed"], case["n_pairs"]), gen.synth_scores(case["seed"], case["n_pairs"])
+        got = harness.evaluate_mjbench(items, scores)
+        assert got["overall_accuracy"] == case["overall_accuracy"], case["seed"]
+        for kind in ("aspect", "criteria"):
+            ref, mine = case[kind], got[kind]
+            for a, b in (("Accuracy", "accuracy"), ("Precision", "precision"), ("Recall", "recall"), ("F1 Score", "f1")):
+                assert mine[b] == ref[a], (case["seed"], kind, a, mine[b], ref[a])
+            for a, b in (("TP", "tp"), ("FP", "fp"), ("TN", "tn"), ("FN", "fn")):
+                assert mine[b] == ref[a], (case["seed"], kind, a)
+                assert sum(mine[b]) == ref[f"{a} Sum"]
+            if "Accuracy per dim" in ref:
+                for a, b in (("Accuracy", "accuracy_dim"), ("Precision", "precision_dim"), ("Recall", "recall_dim"), ("F1 Score", "f1_dim")):
+                    for x, y in zip(mine[b], ref[f"{a} per dim"]):
+                        if y == "nan":
+                            assert math.isnan(x)
+                        else:   # the reference computes these ratios in fp32 tensors
+                            assert abs(x - y) <= 1e-6 * max(1.0, abs(y)), (case["seed"], kind, a, x, y)

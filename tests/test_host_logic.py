@@ -437,3 +437,56 @@ def test_dropin_import_paths():
         assert dp.load_video is video.load_video
     finally:
         sys.path.remove(os.path.join(ROOT, "scripts"))
+
+
+def test_load_video_end_to_end_with_a_stub_decoder(monkeypatch):
+    """data.py:158-179 end to end: ``load_video`` = decode (decord.VideoReader) -> get_index -> per frame dynamic_preprocess +
+    transform -> stacked tiles.  decord is not installed in this image, so a stub module with the three things the path uses
+    (``VideoReader(path, ctx, num_threads)``, ``len``, ``get_avg_fps``, ``vr[i].asnumpy()``) stands in: the run must sample
+    exactly the frames ``get_index`` names (the index function itself is pinned to the reference's, tests/golden/host.json),
+    honour ``bound``, and return the tiles ``load_frames`` gives for those frames."""
+    import sys
+    import types
+
+    n_frames, fps, H, W = 50, 10.0, 72, 96
+    rng = np.random.default_rng(3)
+    clip = rng.integers(0, 256, size=(n_frames, H, W, 3), dtype=np.uint8)
+    opened = []
+
+    class _Frame:
+        def __init__(self, a):
+            self.a = a
+
+        def asnumpy(self):
+            return self.a
+
+    class VideoReader:
+        def __init__(self, path, ctx=None, num_threads=0):
+            opened.append((path, ctx, num_threads))
+            self.read = []
+
+        def __len__(self):
+            return n_frames
+
+        def get_avg_fps(self):
+            return fps
+
+        def __getitem__(self, i):
+            self.read.append(int(i))
+            return _Frame(clip[int(i)])
+
+    stub = types.ModuleType("decord")
+    stub.VideoReader, stub.cpu = VideoReader, (lambda i=0: ("cpu", i))
+    monkeypatch.setitem(sys.modules, "decord", stub)
+
+    for bound, segs, max_num in ((None, 8, 1), ((1.0, 3.5), 4, 1), (None, 3, 4)):
+        idx = video.get_index(bound, fps, n_frames - 1, first_idx=0, num_segments=segs)
+        px, patches = video.load_video("/videos/clip.mp4", bound=bound, input_size=56, max_num=max_num, num_segments=segs)
+        want_px, want_patches = video.load_frames([clip[int(i)] for i in idx], input_size=56, max_num=max_num)
+        assert patches == want_patches and len(patches) == segs
+        assert torch.equal(px, want_px) and px.shape[0] == sum(patches) and px.shape[1:] == (3, 56, 56)
+        frames = video.decode_frames("/videos/clip.mp4", bound=bound, num_segments=segs)
+        assert frames.shape == (segs, H, W, 3) and np.array_equal(frames, clip[np.asarray(idx, dtype=int)])
+    assert all(p == "/videos/clip.mp4" and n == 1 for p, _, n in opened)
+    with pytest.raises(RuntimeError, match="no network"):
+        video.load_video("https://example.com/clip.mp4")

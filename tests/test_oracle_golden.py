@@ -95,3 +95,36 @@ def test_oracle_error_cases():
         ref_cpu.reward_forward(sd, cfg, px, bad, None, synth.IMG_CONTEXT_ID, synth.PAD_ID)
     with pytest.raises(ValueError, match="Cannot handle batch sizes > 1"):
         ref_cpu.reward_forward(sd, cfg, torch.cat([px, px]), torch.cat([ids, ids]), None, synth.IMG_CONTEXT_ID, None)
+
+
+def _ntk_cfg(meta):
+    from mj_video_amd import configuration as C
+    cd = C.tiny_config_dict(meta["image_size"])
+    cd["llm_config"]["max_position_embeddings"] = meta["max_position_embeddings"]
+    cd["llm_config"]["rope_scaling"] = dict(meta["rope_scaling"])
+    return C.InternVLChatRewardModelingConfig(**cd, **C.mjvideo_head_kwargs())
+
+
+def test_oracle_reproduces_the_sticky_dynamic_ntk_sequence():
+    """tests/golden/layers.npz "ntk/*": ONE reference model (max_position_embeddings 48, rope_scaling dynamic) scored
+    short -> long -> short -> a padded batch; its rotary cache regrows on longer inputs and the rescaled inv_freq sticks
+    (modeling_internlm2.py:169-176,204-229), so the third call differs from the first.  The oracle with a rope_state kept
+    across the calls reproduces all four; a fresh state per call reproduces only the calls that regrow the cache."""
+    npz, meta = load_golden("layers")
+    _threads(meta)
+    m = meta["ntk"]
+    cfg = _ntk_cfg(m)
+    sd = synth.synth_state_dict(cfg, seed=m["weight_seed"])
+    names = [c["name"] for c in m["calls"]]
+    state = {}
+    for call in m["calls"]:
+        px, ids, mask, _ = case_inputs(cfg, call["videos"], m["pixel_seed"], m["image_size"])
+        assert int(ids.shape[1]) == call["n_tokens"]
+        out = ref_cpu.reward_forward(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID, rope_state=state)
+        _check(out, npz, f"ntk/{call['name']}", [f"ntk/{n}" for n in names])
+    assert not np.array_equal(npz["ntk/short_first/hidden_state"], npz["ntk/short_again/hidden_state"])
+    # stateless replay of the third call = the FIRST call's numbers, not the third's
+    call = m["calls"][2]
+    px, ids, mask, _ = case_inputs(cfg, call["videos"], m["pixel_seed"], m["image_size"])
+    fresh = ref_cpu.reward_forward(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID)
+    assert np.array_equal(fresh["hidden_state"].float().numpy(), npz["ntk/short_first/hidden_state"])

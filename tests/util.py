@@ -55,3 +55,28 @@ def bf16_ulps(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     ai = torch.where(ai < 0, -(ai & 0x7fff), ai)
     bi = torch.where(bi < 0, -(bi & 0x7fff), bi)
     return (ai - bi).abs()
+
+
+def layer_tensors(cfg, prefix, seed):
+    """the synthetic checkpoint tensors under ``prefix`` with the prefix stripped (same values as synth.synth_state_dict:
+    one Philox stream per key) - for tests that need a few layers of a 2B-dims model, not all 2.2 G parameters"""
+    ls0 = float(cfg.vision_config.initializer_factor)
+    out = {}
+    for key, shape, kind in synth.state_dict_spec(cfg):
+        if not key.startswith(prefix):
+            continue
+        if kind in ("w", "b"):
+            t = synth._normal(seed, key, shape, 0.02)
+        elif kind == "g":
+            t = synth._normal(seed, key, shape, 0.05, 1.0)
+        elif kind == "ls":
+            t = synth._normal(seed, key, shape, 0.05 * ls0, ls0)
+        else:
+            raise AssertionError((key, kind))
+        out[key[len(prefix):]] = t.to(torch.bfloat16)
+    return out
+
+
+def layer_input_rows(seed, tag, shape):
+    """seed-defined bf16 hidden states of the single-layer fixtures (tests/golden/make_layer_fixtures.py)"""
+    return synth._normal(seed, "layer-input/" + tag, shape, 1.0).to(torch.bfloat16)

@@ -32,7 +32,7 @@ def tag_of(k):
     m = re.match(r"t64::gemm_skinny_kernel<(\d)", k)
     if m:
         return "gemm64_" + EPI[int(m.group(1))]
-    m = re.match(r"attn_kernel<(\d+), (true|false)", k)
+    m = re.match(r"(?:v2::attn2_kernel|attn_kernel)<(\d+), (true|false)", k)
     if m:
         return f"attn_d{m.group(1)}" + ("_causal" if m.group(2) == "true" else "")
     for name in ("layernorm", "rmsnorm", "rope_split", "patchify", "embed_gather", "reward_heads", "cls_rows"):
@@ -67,7 +67,19 @@ if json_out:
         if t and f[1] and w[1]:
             per[t] = per.get(t, 0) + 0   # several template instances can share a tag (layernorm<2>, <8>): keep the largest
             per[t] = max(per[t], int((2 * f[0] / f[1] + w[0] / w[1]) * 1024))
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh), C2 workload; "
+    # the library profiles a K-sliced 256-tile GEMM (slices launch + finishing launch) under ONE scope gemm256s_<epilogue>:
+    # emit the matching combined entry (finishing launch + the slices launch that feeds it)
+    for t in [t for t in per if t.startswith("gemm256s_finish_")]:
+        per["gemm256s_" + t[len("gemm256s_finish_"):]] = per[t] + per.get("gemm256s_slices", 0)
+    import hashlib, os
+    h = hashlib.sha1()
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mj-video_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+    json.dump({"source_sha1": h.hexdigest(),   # kernel sources these counters were collected on (bench.py checks it)
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh), C2 workload; "
                          "traffic per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes): the factor 2 is the gfx950 FETCH_SIZE "
                          "correction of MI355X_MICROARCH.md; counted at the L2<->fabric boundary, Infinity-Cache hits included",
                "per_launch_bytes": per}, open(json_out, "w"), indent=1)
