@@ -754,9 +754,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   // next iteration, before the barrier.  M0 (LDS destination, wave-uniform) is written in the statement that uses it.
   const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
   auto dma16 = [&](const char* base, unsigned voff, unsigned lds_dst) __attribute__((always_inline)) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    // (M0 is not saved / restored: nothing else in this kernel uses it - every LDS-DMA is one of these statements - and the
+    // restoring s_mov right behind the DMA cost more than the DMA's own issue)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
                  : "v"(voff), "s"(base), "s"(lds_dst)
                  : "memory");
   };

@@ -1009,6 +1009,307 @@ __global__ __launch_bounds__(512) void splitk_finish256_kernel(GemmArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm256p_kernel (round 3): the same 256 x 256 tile, main loop and epilogue arithmetic as gemm256_kernel, PERSISTENT - one
+// workgroup per CU walks the tiles b, b + grid, b + 2 grid ... of the XCD-aware order - so that a tile's fixed costs stop
+// being paid in series:
+//  * the next tile's first K-tile (64 KiB: all four half-tiles) is requested right after the main loop, into pipeline set 0,
+//    and lands under the epilogue; the next main loop starts from a resident K-tile instead of a 3.5-5 k cycle prologue
+//    (workgroup start, 12 DMA issues, an L2 / fabric round trip with every CU doing the same at once);
+//  * the epilogue no longer owns all of LDS: it runs in two row halves of 128 x 256 through a 66 KiB window over pipeline set 1
+//    (dead after the main loop; set 0 is where the prefetch lands), pass A by the four waves that own the rows, pass B by all;
+//  * the stores of tile i drain under the main loop of tile i + 1 (nothing waits for them until the first counted wait there),
+//    the GELU table is loaded once per workgroup, kernel-argument / launch costs once per CU.
+// Requires an even number of K-tiles >= 4 (the last K-tile then sits in set 1); other problems use gemm256_kernel.
+constexpr int EPI_HALF_BYTES = 128 * EPI_PITCH;                       // 66 KiB window for one 128-row half of the output tile
+constexpr int EPI_WIN_OFF = 4 * HALF_BYTES;                           // = pipeline set 1
+constexpr int GELU_OFF_P = EPI_WIN_OFF + EPI_HALF_BYTES;              // the table sits past the window, untouched by the loops
+static_assert(GELU_OFF_P + GELU_BYTES <= LDS_BYTES, "persistent layout fits the kernel's LDS allocation");
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int n_tiles = p.tiles_m * p.tiles_n;
+  const int nk = p.K / BK;
+
+  const int sw = l15 & 7;
+  int a_off[2], w_off[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    a_off[kk] = l15 * 128 + (((kk * 4 + l4) ^ sw) << 4);
+    w_off[kk] = ((wc & 1) * 64 + l15) * 128 + (((kk * 4 + l4) ^ sw) << 4);
+  }
+  const int a_half = 2 + wr;
+  const int w_half = wc >> 1;
+
+  if constexpr (EPI == MJV_EPI_BIAS_GELU) {   // once per workgroup; older than every DMA the counted waits count
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int chunk = (i * 8 + wave) * 64 + lane;
+      if (chunk < MJV_GELU_TABLE_LEN / 8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const u32x4*)g_gelu_table + chunk),
+                                         (__attribute__((address_space(3))) void*)(smem + GELU_OFF_P + (i * 8 + wave) * 1024), 16, 0, 0);
+    }
+  }
+
+  constexpr int OUT_COLS = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
+  constexpr int LANES_PER_ROW = OUT_COLS / 8;
+  constexpr int ROWS_PER_PASS = 512 / LANES_PER_ROW;
+  constexpr int HPASSES = 128 / ROWS_PER_PASS;          // pass-B passes per row half
+  const int c8 = (tid % LANES_PER_ROW) * 8;
+  const int ml0 = tid / LANES_PER_ROW;
+  const int nlim = (EPI == MJV_EPI_SILU_MUL) ? p.N / 2 : p.N;
+  char* const ewin = smem + EPI_WIN_OFF;
+  const u16* gtab = (const u16*)(smem + GELU_OFF_P);
+
+  bool prefetched = false;
+  int stores_behind = 0;   // store instructions this wave issued after the prefetch of the tile about to start (a lower bound)
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int tm, tn;
+    tile_of_vblock(p, n_tiles, tile, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    StagePtrs sp;   // (recomputed per tile: cheaper than 16 registers carried through the epilogue)
+    init_stage_ptrs(sp, p, m0, n0, wave, lane);
+    const int nout0 = (EPI == MJV_EPI_SILU_MUL) ? n0 / 2 : n0;
+    const int n = nout0 + c8;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x2 braw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      braw[j] = u32x2{0u, 0u};
+      const int nl = wc * 64 + j * 16 + l4 * 4;
+      if (EPI != MJV_EPI_SILU_MUL && p.bias && n0 + nl < p.N) braw[j] = *(const u32x2*)(p.bias + n0 + nl);
+    }
+    u32x4 scraw = {0u, 0u, 0u, 0u};
+    if constexpr (EPI == MJV_EPI_SCALE_RES) {
+      const int ne = n0 + (tid % (OUT_COLS / 8)) * 8;
+      if (p.scale && ne < p.N) scraw = *(const u32x4*)(p.scale + ne);
+    }
+
+    // ---- prologue: K-tile 0 (already requested under the previous tile's epilogue, or requested here), W halves of K-tile 1
+    if (!prefetched) {
+      stage_half<0>(sp, 0, nk, smem, wave);
+      stage_half<1>(sp, 0, nk, smem, wave);
+      stage_half<2>(sp, 0, nk, smem, wave);
+      stage_half<3>(sp, 0, nk, smem, wave);
+    }
+    stage_half<0>(sp, 1, nk, smem, wave);
+    stage_half<1>(sp, 1, nk, smem, wave);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+    // K-tile 0 must have landed.  vmcnt counts loads, stores and DMA together, in issue order: behind the prefetched K-tile 0
+    // this wave has issued the previous tile's pass-B stores (2 * HPASSES of them when that tile was interior - every store
+    // instruction executed) and the 4 DMA instructions just above; allowing exactly that many to stay outstanding waits for
+    // K-tile 0 WITHOUT waiting for the stores to drain (a smaller count is always safe, a larger one never is)
+    if (stores_behind == 2 * HPASSES) {
+      if constexpr (HPASSES == 8) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    MJV_BARRIER();
+    if (wr == 1) MJV_BARRIER();  // stagger the second M-group by one barrier
+
+    bf16x8 af[4][2], wf[2][2][2];
+#define MJV_LOAD_A(MS)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+      af[i][kk] = *(const bf16x8*)(abase + ((MS) * 64 + i * 16) * 128 + a_off[kk]);
+#define MJV_LOAD_W(NS)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+      wf[NS][j][kk] = *(const bf16x8*)(wbase + ((NS) * 32 + j * 16) * 128 + w_off[kk]);
+#define MJV_MFMA_K(MS, NS, KK)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)             \
+      acc[(MS) * 4 + i][(NS) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+          wf[NS][j][KK], af[i][KK], acc[(MS) * 4 + i][(NS) * 2 + j], 0, 0, 0);
+#define MJV_MFMA(MS, NS)                               \
+  __builtin_amdgcn_s_setprio(1);                       \
+  MJV_MFMA_K(MS, NS, 0)                                \
+  MJV_MFMA_K(MS, NS, 1)                                \
+  __builtin_amdgcn_s_setprio(0);
+
+    for (int t = 0; t < nk; ++t) {   // (the two-phase loop of gemm256_kernel, unchanged)
+      const char* abase = smem + ((t & 1) * 4 + a_half) * HALF_BYTES;
+      const char* wbase = smem + ((t & 1) * 4 + w_half) * HALF_BYTES;
+      MJV_LOAD_W(0)
+      MJV_LOAD_W(1)
+      MJV_LOAD_A(0)
+      stage_half<2>(sp, t + 1, nk, smem, wave);
+      stage_half<3>(sp, t + 1, nk, smem, wave);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MJV_BARRIER();
+      MJV_MFMA(0, 0)
+      MJV_MFMA(0, 1)
+      MJV_BARRIER();
+      MJV_LOAD_A(1)
+      stage_half<0>(sp, t + 2, nk, smem, wave);
+      stage_half<1>(sp, t + 2, nk, smem, wave);
+      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MJV_BARRIER();
+      MJV_MFMA(1, 1)
+      MJV_MFMA(1, 0)
+      MJV_BARRIER();
+    }
+    if (wr == 0) MJV_BARRIER();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) in the form the compiler's wait-count pass reads (see gemm256_kernel)
+#undef MJV_LOAD_A
+#undef MJV_LOAD_W
+#undef MJV_MFMA
+#undef MJV_MFMA_K
+
+    // ---- residual rows of this thread's 2 x HPASSES output chunks (issued before the prefetch: their waits must not wait for it)
+    const bool plain = !p.out_rows && p.out_group <= 0 && p.res_mod <= 0;
+    // (one row half at a time: 32 registers instead of 64; the second half's rows are requested when the first half's pass B
+    // has consumed its own - by then the prefetch, older in the queue, has landed)
+    u32x4 rsv[(EPI == MJV_EPI_SCALE_RES) ? 2 * HPASSES : 1];
+    float sc[8];
+    // window row w of half hf <-> tile row (w < 64 ? 0 : 128) + 64 hf + (w & 63): both M-groups of waves take part in every half
+    auto tile_row = [&](int hf, int w) { return ((w >> 6) << 7) + hf * 64 + (w & 63); };
+    if constexpr (EPI == MJV_EPI_SCALE_RES) {
+      unpack8(scraw, sc);
+#pragma unroll
+      for (int it = 0; it < 2 * HPASSES; ++it) {
+        const int ml = tile_row(it / HPASSES, (it % HPASSES) * ROWS_PER_PASS + ml0);
+        rsv[it] = u32x4{0u, 0u, 0u, 0u};
+        if (m0 + ml < p.M && n < nlim) {
+          const int m = p.m_base + m0 + ml;
+          const long rrow = p.res_mod > 0 ? (long)(p.res_off + (m % p.res_mod)) : (long)m;
+          rsv[it] = *(const u32x4*)(p.res + rrow * p.ldr + n);
+        }
+      }
+    }
+
+    // ---- the next tile's first K-tile: requested now (set 0 is dead: its last reader was K-tile nk - 2), lands under the epilogue
+    const int next = tile + (int)gridDim.x;
+    prefetched = false;
+    // (interior tile: every lane of every pass-B store instruction is inside the problem, so all 2 * HPASSES execute)
+    stores_behind = (m0 + BM <= p.M && n0 + BN <= p.N) ? 2 * HPASSES : 0;
+    if (next < n_tiles) {
+      int tm2, tn2;
+      tile_of_vblock(p, n_tiles, next, tm2, tn2);
+      StagePtrs sp_next;
+      init_stage_ptrs(sp_next, p, tm2 * BM, tn2 * BN, wave, lane);
+      stage_half<0>(sp_next, 0, nk, smem, wave);
+      stage_half<1>(sp_next, 0, nk, smem, wave);
+      stage_half<2>(sp_next, 0, nk, smem, wave);
+      stage_half<3>(sp_next, 0, nk, smem, wave);
+      prefetched = true;
+    }
+
+    // ---- epilogue in two row halves through the window over set 1
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      {   // pass A by all eight waves: each wave's fragments 4 hf .. 4 hf + 3 (its rows 64 hf .. 64 hf + 63) -> window rows 64 wr ..
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nl = wc * 64 + j * 16 + l4 * 4;
+          const u32x2 bb = braw[j];
+          const float b4[4] = {__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                               __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+          if (EPI == MJV_EPI_SILU_MUL && (j & 1)) continue;
+          if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+            unsigned ubs[4][4], idx[4][4];
+            bool all_in = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                ubs[i][r] = __float_as_uint(rbf(acc[4 * hf + i][j][r] + b4[r]));
+                const unsigned rel = ((ubs[i][r] >> 16) & 0x7fffu) - MJV_GELU_LO;
+                all_in = all_in && (rel < (unsigned)MJV_GELU_R);
+                idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_R;
+              }
+            if (__all(all_in)) {
+              unsigned t[4][4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[i][r] = gtab[idx[i][r]];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const u32x2 o = {t[i][0] | (t[i][1] << 16), t[i][2] | (t[i][3] << 16)};
+                *(u32x2*)(ewin + (wr * 64 + i * 16 + l15) * EPI_PITCH + nl * 2) = o;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_lut(__uint_as_float(ubs[i][r]), gtab);
+                const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                *(u32x2*)(ewin + (wr * 64 + i * 16 + l15) * EPI_PITCH + nl * 2) = o;
+              }
+            }
+            continue;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v[4];
+            int col;
+            if constexpr (EPI == MJV_EPI_SILU_MUL) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = rbf(silu(rbf(acc[4 * hf + i][j][r]))) * rbf(acc[4 * hf + i][j + 1][r]);
+              col = wc * 32 + (j >> 1) * 16 + l4 * 4;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc[4 * hf + i][j][r] + b4[r];
+              if constexpr (EPI == MJV_EPI_BIAS_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              col = nl;
+            }
+            const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+            *(u32x2*)(ewin + (wr * 64 + i * 16 + l15) * EPI_PITCH + col * 2) = o;
+          }
+        }
+      }
+      __syncthreads();
+      // pass B by all eight waves: window rows it * ROWS_PER_PASS + ml0
+      u32x4 vals[HPASSES];
+#pragma unroll
+      for (int it = 0; it < HPASSES; ++it) vals[it] = *(const u32x4*)(ewin + (it * ROWS_PER_PASS + ml0) * EPI_PITCH + c8 * 2);
+#pragma unroll
+      for (int it = 0; it < HPASSES; ++it) {
+        const int ml = tile_row(hf, it * ROWS_PER_PASS + ml0);
+        if (m0 + ml >= p.M || n >= nlim) continue;
+        u32x4 val = vals[it];
+        if constexpr (EPI == MJV_EPI_SCALE_RES) {
+          float v[8], rs[8];
+          unpack8(val, v);
+          if (p.scale) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * sc[e]);
+          }
+          unpack8(rsv[hf * HPASSES + it], rs);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rs[e];
+          val = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        }
+        u16* dst = p.C + (plain ? (long)(p.m_base + m0 + ml) : out_row_of(p, p.m_base + m0 + ml)) * p.ldc + n;
+        if (p.nt_store) __builtin_nontemporal_store(val, (u32x4*)dst);
+        else *(u32x4*)dst = val;
+      }
+      __syncthreads();   // the window is rewritten by the next half / refilled by the next tile's K-tile 1
+    }
+  }
+}
+
 }  // namespace t256
 
 thread_local int g_num_cus = 256;   // CUs of the device of the call in flight (mjv_device_cus), set in mjv_gemm_bf16
@@ -1060,6 +1361,8 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
 #endif
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<MJV_EPI_BIAS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+    if constexpr (EPI != MJV_EPI_ROPE_QKV)
+      (void)hipFuncSetAttribute((const void*)t256::gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     attr_done.fetch_or(bit, std::memory_order_release);   // racing first calls both set the attributes: idempotent
   }
   if (big) {
@@ -1079,8 +1382,27 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
     else if (MJV_TUNE(variant) == 3)
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
 #endif
-    else
+    else {
+      // persistent form (one workgroup per CU walks the tiles, next tile's first K-tile prefetched under the epilogue) when the
+      // launch has more tiles than CUs and an even number (>= 4) of K-tiles; the rotary epilogue keeps the one-tile kernel
+      const int tiles = a.tiles_m * a.tiles_n, nk = a.K / 64;
+      // (measured per epilogue, tools/gemm_bench.py 1000 / 1009 in one process: +1.4 ... +2.1 % for the plain-bias and SiLU
+      // epilogues; the LayerScale / residual epilogue loses 6-24 % - its 64 residual registers on top of the persistent
+      // loop's state spill - and the GELU epilogue 29 % - half the table gathers in flight per vote - so those keep the
+      // one-tile kernel)
+      bool persistent = (EPI == MJV_EPI_BIAS || EPI == MJV_EPI_BIAS_RELU || EPI == MJV_EPI_SILU_MUL) && tiles > g_num_cus &&
+                        nk >= 4 && (nk & 1) == 0;
+#ifdef MJV_BENCH
+      if (MJV_TUNE(variant) == 9) persistent = false;   // A/B: the one-tile-per-workgroup kernel
+#endif
+      if constexpr (EPI != MJV_EPI_ROPE_QKV) {
+        if (persistent) {
+          hipLaunchKernelGGL((t256::gemm256p_kernel<EPI>), dim3(g_num_cus), dim3(512), t256::LDS_BYTES, s, a);
+          return mjv_check_launch("gemm_bf16");
+        }
+      }
       hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+    }
   } else {
     a.tiles_m = (a.M + 127) / 128;
     a.tiles_n = (a.N + 127) / 128;
