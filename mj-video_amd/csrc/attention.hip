@@ -647,7 +647,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 
   // this wave's queries: sub-block A = qw0 + l31, B = qw0 + 32 + l31 (sequence-relative indices)
   const int qw0 = cls_block ? 0 : (peel ? 1 : 0) + qb * QBW + wave * QW;
-  const int nq_wave = cls_block ? (wave == 0 ? 1 : 0) : max(0, min(QW, len - qw0));   // valid queries of this wave
+  // (query-0 block: waves 0 and 1 both hold the query and each takes one 32-key half of every tile - the state of wave 1 is
+  // merged into wave 0's after the loop; a single wave walking all 1024 keys held the block's slot twice as long)
+  const int nq_wave = cls_block ? (wave < 2 ? 1 : 0) : max(0, min(QW, len - qw0));   // valid queries of this wave
   const bool hasA = nq_wave > 0, hasB = NSUB == 2 && nq_wave > 32;
   int qi[NSUB];
   qi[0] = cls_block ? 0 : qw0 + l31;
@@ -686,9 +688,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   const char* const k_seq = (const char*)(Kg + (long)(s0 + (peel ? 1 : 0)) * p.ldk);   // key row 0 of the tiles
   const char* const v_seq = (const char*)(Vg + (long)(s0 + (peel ? 1 : 0)) * p.ldv);
 
-  if (peel && hasA) {
+  if (peel && hasA && !(cls_block && wave == 1)) {
     // key 0 as the initial state.  s = q . k_0 in fp32 (this lane's 8-element groups, then the other half-lane's), rounded
-    // like every score; M = ceil(s c); p_0 = exp2(s c - M) in (1/2, 1]; l = p_0 (counted in the hi = 0 lane only: row sums
+    // like every score; M = ceil(s c); p_0 = exp2(s c - M) in (1/2, 1]; l = bf16(p_0) (counted in the hi = 0 lane only: row sums
     // are lane-partial); O = bf16(p_0) * v_0 - what the MFMA would have accumulated for this key.
     const u16* k0p = Kg + (long)s0 * p.ldk + 8 * hi;
     const u16* v0p = Vg + (long)s0 * p.ldv;
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
       const float p0 = __builtin_amdgcn_exp2f(arg - m0);
       const float pb = rbf(p0);
       Mq[sb] = m0;
-      lsum[sb] = hi == 0 ? p0 : 0.f;
+      lsum[sb] = hi == 0 ? pb : 0.f;
 #pragma unroll
       for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
@@ -805,7 +807,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   const f32x2 scale2 = {p.scale, p.scale};
 
   // one pair of scores of a unit -> two exponentials (in place of nothing: the scores stay live for a possible redo)
-  auto do_pair = [&](const f32x16& S, int r, float nmb, f32x2& psum, unsigned& pw) __attribute__((always_inline)) {
+  // The row sum takes the ROUNDED probabilities (v_dot2c_f32_bf16 of the packed pair with (1, 1)): numerator and denominator
+  // of O = sum p~ v / sum p~ then carry the same rounding, so the weights sum to one exactly - with an integer offset the
+  // largest probability of a row is no longer exactly 1, and a sum of the unrounded values left its rounding error in O
+  // (rows dominated by one key: short causal rows, peaked heads).  One VOP2 per pair instead of a v_pk_add_f32.
+  auto do_pair = [&](const f32x16& S, int r, float nmb, float& psum, unsigned& pw) __attribute__((always_inline)) {
     const f32x2 a2 = {S[r], S[r + 1]};
     f32x2 sr;
     if constexpr (RM == RM_MUL) sr = round_pair(a2 * scale2);
@@ -815,11 +821,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     }
     const f32x2 e2 = sr * c2 + f32x2{nmb, nmb};
     const f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
-    psum += pv;
     pw = pack_pair(pv);
+    psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, pw), __builtin_bit_cast(bf16x2v, 0x3f803f80u), psum, false);
   };
   // rare path: raise the offset of sub-block sb to cover unit scores S, rescale its state, recompute the unit's P
-  auto redo = [&](const f32x16& S, auto sbc, f32x2& psum, unsigned (&pw)[8]) __attribute__((always_inline)) {
+  auto redo = [&](const f32x16& S, auto sbc, float& psum, unsigned (&pw)[8]) __attribute__((always_inline)) {
     constexpr int sb = decltype(sbc)::value;
     float mx = S[0];
 #pragma unroll
@@ -835,7 +841,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[sb][i][r] *= alpha;
     Mq[sb] = mn;
-    psum = f32x2{0.f, 0.f};
+    psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) do_pair(S, r, -mn, psum, pw[r >> 1]);
   };
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
       const int nboff = ((kt + 1) & 1) * TB;
       f32x16 S[U];
       unsigned Pw[U][8];
-      f32x2 psum[U];
+      float psum[U];
       constexpr int NS = 2 * U * F, AHEAD = 3, RING = 4;
       bf16x8 ring[RING];
       auto rd = [&](auto ic) __attribute__((always_inline)) {
@@ -901,18 +907,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
           constexpr int us = s - 1;                                     // unit whose softmax runs in this slot
           constexpr int j = i - slot_first<F, U>(s), cnt = slot_size<F, U>(s);
           constexpr int pr0 = j * 8 / cnt, pr1 = (j + 1) * 8 / cnt;     // pairs [pr0, pr1) of the unit's 8
-          if constexpr (j == 0) psum[us] = f32x2{0.f, 0.f};
+          if constexpr (j == 0) psum[us] = 0.f;
           constexpr int sbs = (U == 4) ? (us & 1) : 0;
           const float nmb = -Mq[sbs];
 #pragma unroll
           for (int pr = pr0; pr < pr1; ++pr) do_pair(S[us], 2 * pr, nmb, psum[us], Pw[us][pr]);
           if constexpr (j == cnt - 1) {
-            float tot = psum[us][0] + psum[us][1];
-            if (__any(!(tot < BIGSUM))) {
-              redo(S[us], std::integral_constant<int, sbs>{}, psum[us], Pw[us]);
-              tot = psum[us][0] + psum[us][1];
-            }
-            lsum[sbs] += tot;
+            if (__any(!(psum[us] < BIGSUM))) redo(S[us], std::integral_constant<int, sbs>{}, psum[us], Pw[us]);
+            lsum[sbs] += psum[us];
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -930,16 +932,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
       constexpr int sb = (NSUB == 2) ? (u & 1) : 0, h = (NSUB == 2) ? (u >> 1) : u;
       const int kb = k0 + 32 * h;
       const int q_last = qw0 + 32 * sb + min(31, nq_wave - 32 * sb - 1);   // last valid query of the sub-block
-      if ((sb == 1 && !hasB) || kb >= klen || (CAUSAL && kb > q_last)) return;   // wave-uniform
+      if ((sb == 1 && !hasB) || kb >= klen || (CAUSAL && kb > q_last) || (cls_block && h != wave)) return;   // wave-uniform
+      // every fragment of the unit is requested up front (K for the scores, V for the second product): read where they
+      // are used, each product paid an LDS round trip per MFMA - 1 775 cycles for one unit in the query-0 block
+      bf16x8 kf[F], vf[F];
+#pragma unroll
+      for (int ks = 0; ks < F; ++ks) read_k(h, ks, kf[ks]);
+      constexpr bool V_EARLY = D == 64;    // (at D = 128 sixteen fragments up front cost spilled registers: V follows the softmax)
+      if constexpr (V_EARLY) {
+#pragma unroll
+        for (int f_ = 0; f_ < F; ++f_) read_v(h, f_, vf[f_]);
+      }
       f32x16 S;
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < F; ++ks) {
-        bf16x8 kf;
-        read_k(h, ks, kf);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sb][ks], S, 0, 0, 0);
-      }
+      for (int ks = 0; ks < F; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[sb][ks], S, 0, 0, 0);
       const int qmin = qw0 + 32 * sb;
       if (kb + 32 > klen || (CAUSAL && kb + 31 > qmin)) {
 #pragma unroll
@@ -949,22 +957,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
         }
       }
       unsigned pw[8];
-      f32x2 ps = {0.f, 0.f};
+      float ps = 0.f;
       const float nmb = -Mq[sb];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) do_pair(S, r, nmb, ps, pw[r >> 1]);
-      float tot = ps[0] + ps[1];
-      if (__any(!(tot < BIGSUM))) {
-        redo(S, std::integral_constant<int, sb>{}, ps, pw);
-        tot = ps[0] + ps[1];
-      }
-      lsum[sb] += tot;
+      if (__any(!(ps < BIGSUM))) redo(S, std::integral_constant<int, sb>{}, ps, pw);
+      lsum[sb] += ps;
+      if constexpr (!V_EARLY) {
 #pragma unroll
-      for (int f_ = 0; f_ < F; ++f_) {
-        bf16x8 vf;
-        read_v(h, f_, vf);
-        oacc[sb][f_ >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfrag(pw, f_ & 1), oacc[sb][f_ >> 1], 0, 0, 0);
+        for (int f_ = 0; f_ < F; ++f_) read_v(h, f_, vf[f_]);
       }
+#pragma unroll
+      for (int f_ = 0; f_ < F; ++f_)
+        oacc[sb][f_ >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[f_], pfrag(pw, f_ & 1), oacc[sb][f_ >> 1], 0, 0, 0);
     });
   };
 
@@ -1002,7 +1007,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     for (int g = 0; g < D / 32; ++g) vboff[g] ^= TB;
   };
   // leading tiles that are whole (all 64 keys exist) and need no mask for any query of this wave
-  const int n_whole = !hasA ? 0 : min(n_tiles, CAUSAL ? max(0, (qw0 + 1) / KB) : klen / KB);
+  const int n_whole = (!hasA || cls_block) ? 0 : min(n_tiles, CAUSAL ? max(0, (qw0 + 1) / KB) : klen / KB);
   int kt = 0;
   if (NSUB == 2 && hasB) {
     if constexpr (NSUB == 2)
@@ -1022,6 +1027,30 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     d[14] = (unsigned long long)((hasA ? 1 : 0) + ((hasB || (NSUB == 1 && hasA)) ? 1 : 0) + (cls_block ? 4 : 0));
   }
 #endif
+  if (cls_block) {   // workgroup-uniform: merge wave 1's state (the second key half of every tile) into wave 0's
+    __syncthreads();                                 // every wave is out of the tile loop: the K / V buffers are free
+    float* mb = (float*)smem;
+    constexpr int REC = 2 + 16 * (D / 32);
+    if (wave == 1 && l31 == 0) {
+      mb[hi * REC] = Mq[0];
+      mb[hi * REC + 1] = lsum[0];
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mb[hi * REC + 2 + dt * 16 + r] = oacc[0][dt][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const float m1 = mb[hi * REC], l1 = mb[hi * REC + 1];
+      const float mn = fmaxf(Mq[0], m1);              // integer offsets: both factors are exact powers of two (or 0)
+      const float a0 = __builtin_amdgcn_exp2f(Mq[0] - mn), a1 = (m1 > -INFINITY) ? __builtin_amdgcn_exp2f(m1 - mn) : 0.f;
+      lsum[0] = lsum[0] * a0 + l1 * a1;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[0][dt][r] = oacc[0][dt][r] * a0 + mb[hi * REC + 2 + dt * 16 + r] * a1;
+    }
+  }
   // ---- epilogue: O[query][d] = O^T / l ; lane = query, register r <-> d = 32 dt + (r & 3) + 8 (r >> 2) + 4 hi
 #pragma unroll
   for (int sb = 0; sb < NSUB; ++sb) {
