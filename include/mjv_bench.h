@@ -25,6 +25,12 @@ int mjv_bench_gemm_stamp_buffer(void* device_buffer);
  * 2 = softmax removed, 3 = MFMAs removed - wrong results; 6 = attn2_kernel with two waves per workgroup (correct). */
 int mjv_bench_attention_set(int32_t variant);
 
+/* RMSNorm with the row statistics supplied by the producer: partials = [rows][8] fp32 per-n-tile sums of squares (dim 2048),
+ * summed in tile order.  Exists to measure what emitting the statistics from the EPI_SCALE_RES epilogue could return
+ * (tools/norm_ab.py; DESIGN "Norm fusion"). */
+int mjv_bench_rmsnorm_prestat(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy, const mjv_bf16* w,
+                              const float* partials, int32_t rows, int32_t dim, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,7 @@ BENCH_SYMBOLS = {
     "mjv_bench_gemm_set": (C.c_int, [_I32]),
     "mjv_bench_gemm_stamp_buffer": (C.c_int, [_VP]),
     "mjv_bench_attention_set": (C.c_int, [_I32]),
+    "mjv_bench_rmsnorm_prestat": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, C.c_float, _VP]),
 }
 BENCH_LIB_PATH = os.path.join(_PKG_DIR, "libmjv_hip_bench.so")
 

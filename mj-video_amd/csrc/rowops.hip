@@ -82,10 +82,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
 
 // ------------------------------------------------------------------------------------------ RMSNorm
 // modeling_internlm2.py:138-143: h = bf16(x32 * rsqrt(mean(x32^2) + eps)); y = bf16(w * h)
-template <int IT>
+// PARTS > 0 (bench build only, the A/B of DESIGN "Norm fusion"): the row's sum of squares arrives as PARTS per-n-tile partial
+// sums from the producing GEMM's epilogue ([rows][PARTS] fp32, summed here in tile order) instead of being reduced in here
+template <int IT, int PARTS = 0>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ y, long ldy,
                                                       const u16* __restrict__ w, const int* __restrict__ row_index,
-                                                      int rows, int dim, float eps) {
+                                                      int rows, int dim, float eps, const float* __restrict__ partials = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -97,11 +99,20 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* __restrict__ x,
     const int c = it * 512 + lane * 8;
     if (c < dim) {
       unpack8(*(const u32x4*)(x + srow * ldx + c), v[it]);
+      if constexpr (PARTS == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sq += v[it][j] * v[it][j];
+        for (int j = 0; j < 8; ++j) sq += v[it][j] * v[it][j];
+      }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)dim + eps);
+  float total;
+  if constexpr (PARTS == 0) total = wave_sum(sq);
+  else {
+    total = 0.f;
+#pragma unroll
+    for (int t = 0; t < PARTS; ++t) total += partials[srow * PARTS + t];
+  }
+  const float rstd = rsqrtf(total / (float)dim + eps);
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int c = it * 512 + lane * 8;
@@ -226,6 +237,20 @@ extern "C" int mjv_rmsnorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int
     hipLaunchKernelGGL(rmsnorm_kernel<MAX_IT>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w, row_index, rows, dim, eps);
   return mjv_check_launch("rmsnorm");
 }
+
+#ifdef MJV_BENCH
+// A/B for DESIGN "Norm fusion": RMSNorm whose statistics come from the producer (8 per-n-tile partial sums of squares per row,
+// what an EPI_SCALE_RES epilogue of a 2048-wide output would emit).  dim 2048 only.
+extern "C" int mjv_bench_rmsnorm_prestat(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy, const mjv_bf16* w,
+                                         const float* partials, int32_t rows, int32_t dim, float eps, void* stream) {
+  MJV_REQUIRE(x && y && w && partials && dim == 2048, "rmsnorm_prestat: dim 2048 only");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((rows + WAVES - 1) / WAVES);
+  hipLaunchKernelGGL((rmsnorm_kernel<4, 8>), grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w, (const int*)nullptr, rows, dim, eps,
+                     partials);
+  return mjv_check_launch("rmsnorm_prestat");
+}
+#endif
 
 extern "C" int mjv_rope_split_bf16(const mjv_bf16* qkv, int64_t ldqkv, mjv_bf16* q, int64_t ldq, mjv_bf16* k, int64_t ldk,
                                    const mjv_bf16* cos_tab, const mjv_bf16* sin_tab, const int32_t* positions,

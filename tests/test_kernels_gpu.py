@@ -131,6 +131,36 @@ def test_gemm_silu_mul(cuda, tile):
     assert_close_bf16(out, ref, 3, frac_exact=0.95, atol=2e-3, what="gemm_silu_mul")
 
 
+@pytest.mark.parametrize("K", [256, 1024])
+@pytest.mark.parametrize("epi", ["bias", "silu_mul"])
+def test_gemm_persistent_equals_one_tile_kernel(cuda, epi, K):
+    """round 3: launches of the plain-bias / SiLU epilogues with more 256^2 tiles than CUs run the PERSISTENT kernel
+    (gemm256p_kernel: tiles walked by one workgroup per CU, the next tile's first K-tile prefetched under a two-half epilogue).
+    Same MFMA order and rounding points as the one-tile kernel, so: 16 384 x 2 048 outputs in ONE launch (512 tiles ->
+    persistent) must equal, bit for bit, the same rows computed as two launches of 256 tiles each (one-tile kernel) - and the
+    integer-data case must be exact."""
+    from mj_video_amd import ops
+    M, N = 16384, 2048
+    a = rnd(M, K, seed=11).to(cuda)
+    w = rnd(N, K, std=0.05, seed=12).to(cuda)
+    b = rnd(N, std=0.1, seed=13).to(cuda)
+    code = ops.EPI_BIAS if epi == "bias" else ops.EPI_SILU_MUL
+    cols = N if epi == "bias" else N // 2
+    kw = dict(bias=b) if epi == "bias" else {}
+    one = torch.empty(M, cols, dtype=BF, device=cuda)
+    ops.gemm(a, w, one, code, tile=256, **kw)
+    two = torch.empty(M, cols, dtype=BF, device=cuda)
+    for h in range(2):
+        ops.gemm(a[h * M // 2:(h + 1) * M // 2], w, two[h * M // 2:(h + 1) * M // 2], code, tile=256, **kw)
+    assert torch.equal(one, two)
+    if epi == "bias":
+        g = torch.Generator().manual_seed(5)
+        ai = torch.randint(-4, 5, (M, K), generator=g).float().to(BF)
+        wi = torch.randint(-3, 4, (N, K), generator=g).float().to(BF)
+        ops.gemm(ai.to(cuda), wi.to(cuda), one, ops.EPI_BIAS, tile=256)
+        assert torch.equal(one.cpu(), (ai.float() @ wi.float().t()).to(BF))
+
+
 # ---------------------------------------------------------------------------------------- row kernels
 @pytest.mark.parametrize("rows,dim", [(5, 128), (1025, 1024), (300, 4096)])
 def test_layernorm(cuda, rows, dim):

@@ -21,6 +21,9 @@ def tag_of(k):
     m = re.match(r"t256::gemm256_kernel<(\d), 0>", k)
     if m:
         return "gemm256_" + EPI[int(m.group(1))]
+    m = re.match(r"t256::gemm256p_kernel<(\d)>", k)      # persistent form of the same tile kernel (round 3): same profiler tag
+    if m:
+        return "gemm256_" + EPI[int(m.group(1))]
     if re.match(r"t256::gemm256_kernel<0, 7>", k):
         return "gemm256s_slices"        # K-sliced 256-tile launch: fp32 slice images to the workspace
     m = re.match(r"t256::splitk_finish256_kernel<(\d)>", k)
