@@ -22,7 +22,7 @@ int mjv_bench_gemm_set(int32_t code);
  * cycles} to this device buffer; NULL = off */
 int mjv_bench_gemm_stamp_buffer(void* device_buffer);
 /* attention: 0 = production; on the two production shapes of the round-2 kernel (desc.kernel = 5) 1 = K/V staged once,
- * 2 = softmax removed, 3 = MFMAs removed - wrong results; 6 = attn2_kernel with two waves per workgroup (correct). */
+ * 2 = softmax removed, 3 = MFMAs removed - wrong results. */
 int mjv_bench_attention_set(int32_t variant);
 
 /* RMSNorm with the row statistics supplied by the producer: partials = [rows][8] fp32 per-n-tile sums of squares (dim 2048),

@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 }  // namespace v2
 
 #ifdef MJV_BENCH
-int g_attn_bench = 0;   // bench library only (mjv_bench_attention_set): timing variants 1-3 of the round-2 kernel, 6 = NW 2
+int g_attn_bench = 0;   // bench library only (mjv_bench_attention_set): timing variants 1-3 of the round-2 kernel
 #endif
 
 template <int D, bool CAUSAL>
@@ -1108,11 +1108,13 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
       else if (pow2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_POW2, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
       else hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_MUL, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
     };
-#ifdef MJV_BENCH
-    if (g_attn_bench == 6) go(std::integral_constant<int, 2>{});
-    else
-#endif
-      go(std::integral_constant<int, 4>{});
+    // Four waves per workgroup; two (half as many queries per block) only on request (desc.kernel 6).  Measured for the one
+    // launch size where the smaller block could pay - ONE video per forward, 144 causal blocks of 256 queries on 256 CUs:
+    // 1.43 ms of causal attention per video with two waves against 1.28 ms with four (tools/single_video_profile.py); every
+    // block stages all its keys, so halving the block doubles the staging per query
+    const bool small = kernel == 6;
+    if (small) go(std::integral_constant<int, 2>{});
+    else go(std::integral_constant<int, 4>{});
     return mjv_check_launch("attention");
   }
   // LDS-DMA staging up to 4096 keys per sequence (measured +2 ... +3 % at 1025 / 2186, 0 at 2048 non-causal); beyond that
@@ -1141,10 +1143,10 @@ extern "C" int mjv_attention_stamp_buffer(void* p) {
 
 #ifdef MJV_BENCH
 // bench library only: 0 = production; 1-3 = timing variants of the round-2 kernel on the two production shapes (K/V staged
-// once / softmax removed / MFMAs removed: wrong results by construction); 6 = attn2_kernel with two waves per workgroup
+// once / softmax removed / MFMAs removed: wrong results by construction)
 extern "C" int mjv_bench_attention_set(int32_t v) {
-  if (v != 0 && v != 1 && v != 2 && v != 3 && v != 6) {
-    mjv_set_error("bench_attention_set: %d not in {0, 1, 2, 3, 6}", v);
+  if (v != 0 && v != 1 && v != 2 && v != 3) {
+    mjv_set_error("bench_attention_set: %d not in {0, 1, 2, 3}", v);
     return MJV_E_ARG;
   }
   g_attn_bench = v;
@@ -1155,7 +1157,7 @@ extern "C" int mjv_bench_attention_set(int32_t v) {
 extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
   MJV_REQUIRE(d && d->Q && d->K && d->V && d->O && d->cu_seqlens, "attention: null pointer");
   MJV_REQUIRE(d->head_dim == 64 || d->head_dim == 128, "attention: head_dim %d not in {64,128}", d->head_dim);
-  MJV_REQUIRE(d->kernel == 0 || d->kernel == 4 || d->kernel == 5, "attention: kernel %d not in {0, 4, 5}", d->kernel);
+  MJV_REQUIRE(d->kernel == 0 || (d->kernel >= 4 && d->kernel <= 7), "attention: kernel %d not in {0, 4, 5, 6, 7}", d->kernel);
   MJV_REQUIRE(d->n_seqs > 0 && d->max_seqlen > 0 && d->n_heads > 0 && d->kv_group > 0, "attention: bad sizes");
   MJV_REQUIRE(d->n_heads % d->kv_group == 0, "attention: n_heads %% kv_group != 0");
   MJV_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "attention: ld alignment");

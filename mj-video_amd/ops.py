@@ -150,11 +150,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
 
 
 def attention_set_variant(v: int) -> None:
-    """This THREAD's default attention kernel: 0 automatic, 4 = register-staged round-1 kernel, 5 = round-2 choice (all
-    correct; tests A/B them).  1-3 and 6 are measurement variants of the bench build (process-wide, bench library only)."""
+    """This THREAD's default attention kernel: 0 automatic, 4 = register-staged round-1 kernel, 5 = round-2 choice, 6 / 7 =
+    round-3 kernel with two / four waves per workgroup (all correct; tests A/B them).  1-3 are measurement variants of the
+    bench build (process-wide, bench library only)."""
     lib = load_library()
     bench = getattr(getattr(lib, "mjv_bench_attention_set", None), "argtypes", None) is not None
-    if v in (0, 4, 5):
+    if v in (0, 4, 5, 6, 7):
         _tls.attn_kernel = v
         if bench:
             check(lib.mjv_bench_attention_set(0), "mjv_bench_attention_set")
