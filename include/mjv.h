@@ -124,8 +124,8 @@ typedef struct mjv_attn_desc {
   int32_t causal;
   float scale;
   int32_t score_round_mode;
-  int32_t kernel;             /* 0 = automatic (round 3: the two-sub-block pipelined kernel up to 4096 keys per sequence, the
-                                 register-staged round-1 kernel beyond); 4 = the register-staged kernel for every shape;
+  int32_t kernel;             /* 0 = automatic (round 3: the two-sub-block pipelined kernel); 4 = the register-staged round-1
+                                 kernel for every shape;
                                  5 = the round-2 choice (its LDS-DMA form up to 4096 keys); 6 / 7 = the round-3 kernel with two /
                                  four waves (128 / 256 queries at head_dim 64, 64 / 128 at 128) per workgroup (automatic = four;
                                  bit-identical results).  Every choice gives correct results: the tests A/B them.  Other

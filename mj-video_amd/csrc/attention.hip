@@ -1092,9 +1092,11 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
     if (g_attn_bench == 3) { hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RMX, 3>), grid, dim3(256), 0, s, a); return mjv_check_launch("attention"); }
   }
 #endif
-  // round 3: the two-sub-block pipelined kernel (attn2_kernel) for sequences of up to 4096 keys; variant 5 = the round-2 choice
-  const bool dma = max_seqlen <= 4096 && kernel != 4;   // kernel 4: the register-staged kernel for EVERY shape
-  if (dma && kernel != 5) {
+  // round 3: attn2_kernel for every length (measured against the round-2 choice in one process, causal D = 128: 8 192 keys
+  // 0.578 vs 0.656 ms, 28 810 keys - BASELINE configs[3] - 3.31 vs 3.76 ms = 1 027 vs 903 TFLOP/s); kernel 4 = the
+  // register-staged round-1 kernel, 5 = the round-2 choice (its LDS-DMA form up to 4096 keys, register-staged beyond)
+  const bool dma = max_seqlen <= 4096 && kernel != 4;
+  if (kernel != 4 && kernel != 5) {
     constexpr int NSUB = (D == 64) ? 2 : 1;
     auto go = [&](auto nwc) {
       constexpr int NW = decltype(nwc)::value;

@@ -41,4 +41,5 @@ for rnd in range(rounds):
             print("variant", v, end="  "); run("d128_L2048", 8, 2048, 16, 2, 128, False, 1)
             print("variant", v, end="  "); run("d128c_L2048", 8, 2048, 16, 2, 128, True, 1)
             print("variant", v, end="  "); run("d128c_L8192", 2, 8192, 16, 2, 128, True, 1)
+            print("variant", v, end="  "); run("d128c_L28810", 1, 28810, 16, 2, 128, True, 1)
 ops.attention_set_variant(0)
