@@ -741,6 +741,44 @@ def test_collated_batch_layout(cuda):
             assert dlt <= tol, (i, f, dlt, tol)
 
 
+def test_random_batch_compositions_against_the_oracle(cuda):
+    """tiny dims, 12 random batches - 1 to 4 videos, 1 to 5 tiles each, caption lengths from 1 to 60 tokens (so right-padded
+    rows of very different lengths, prompts whose gating token sits at different offsets), interleaved or blocked frame
+    prefixes - scored by the HIP path and by the oracle (bf16, CPU) on the very same tensors.  Every head output within the
+    tiny-dims noise bound of the reference-executed fixtures; fresh weights per batch."""
+    import random
+    from mj_video_amd import synth
+    from mj_video_amd.chat_input import num_image_tokens_per_tile
+    from oracle import ref_cpu
+    tiny_npz, tiny_meta = load_golden("tiny")
+    names = [c["name"] for c in tiny_meta["cases"]]
+    rng = random.Random(31)
+    cfg = make_cfg("tiny", 56)
+    per = num_image_tokens_per_tile(cfg)
+    worst = {}
+    for it in range(12):
+        sd = synth.synth_state_dict(cfg, seed=100 + it, dtype=torch.float32)
+        model = build_hip_model(cfg, sd, cuda)
+        sd_bf = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+        B = rng.randint(1, 4)
+        tiles = [rng.randint(1, 5) for _ in range(B)]
+        px = torch.cat([synth.synth_pixel_values(200 + it, b, tiles[b], 56) for b in range(B)])
+        rows = [synth.synth_input_ids(per * tiles[b], 300 + 10 * it + b, n_caption=rng.randint(1, 60),
+                                      interleave_frames=(tiles[b] if rng.random() < 0.5 else None)) for b in range(B)]
+        ids, mask = synth.pad_batch(rows, length=max(int(r.shape[-1]) for r in rows) + rng.choice([0, 0, 7, 40]))
+        out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+        orc = ref_cpu.reward_forward(sd_bf, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID)
+        for f in ("score", "aspect_scores", "rewards", "aspect_gating_output", "aspect_weights", "criteria_gating_output",
+                  "hidden_state", "prompt_embedding"):
+            got = getattr(out, f).float().cpu()
+            assert torch.isfinite(got).all(), (it, f)
+            tol = TOL_FACTOR * noise_floor(tiny_npz, names, f) + ATOL_FLOOR
+            dlt = float((got - orc[f].float()).abs().max())
+            worst[f] = max(worst.get(f, 0.0), dlt / tol)
+            assert dlt <= tol, (it, B, tiles, f, dlt, tol)
+    print("random batches: worst deviation / tolerance per field", {k: round(v, 3) for k, v in worst.items()})
+
+
 def test_eval_driver_protocol(cuda):
     """scripts/eval/eval_genai_mjvideo.py: batched scoring of (caption, left, right, vote) examples through
     prepare_chat_input + device preprocessing gives the same scores as the reference's protocol (one forward per video,
