@@ -33,6 +33,26 @@ def test_device_preprocessing_is_bit_exact(cuda, H, W, max_num, expect_tiles):
     assert torch.equal(got.cpu(), ref.to(torch.bfloat16))
 
 
+def test_device_preprocessing_random_geometries(cuda):
+    """25 random frame sizes (16 .. 1600 pixels a side: extreme aspect ratios, down- and up-scaling, odd sizes) x max_num in
+    {1, 4, 6, 12} x input_size in {448, 224, 56}: tile counts equal and every bf16 bit equal to Pillow + the host transform"""
+    import random
+    rng = random.Random(5)
+    nrng = np.random.default_rng(5)
+    for it in range(25):
+        H, W = rng.choice([16, 17, 100, 333, 448, 720, 1080, rng.randint(16, 1600)]), rng.choice([16, 31, 200, 448, 854, 1280, 1920, rng.randint(16, 1600)])
+        max_num = rng.choice([1, 1, 4, 6, 12])
+        size = rng.choice([448, 448, 224, 56])
+        if max_num > 1 and size == 448 and H * W > 1500 * 1500:
+            max_num = 6
+        frames = [nrng.integers(0, 256, size=(H, W, 3), dtype=np.uint8) for _ in range(2)]
+        ref, counts = video.load_frames(frames, input_size=size, max_num=max_num)
+        got, gcounts = video.load_frames_device(torch.from_numpy(np.stack(frames)).to(cuda), input_size=size, max_num=max_num)
+        assert gcounts == counts, (H, W, max_num, size, gcounts, counts)
+        assert got.shape == ref.shape, (H, W, max_num, size)
+        assert torch.equal(got.cpu(), ref.to(torch.bfloat16)), (H, W, max_num, size, int((got.cpu() != ref.to(torch.bfloat16)).sum()))
+
+
 def test_device_preprocessing_feeds_the_model(cuda):
     """uint8 frames -> device preprocessing -> reward forward: same scores as the host-preprocessed path (bitwise)"""
     from util import build_hip_model, make_cfg
