@@ -333,6 +333,7 @@ class InternVLChatRewardModeling(nn.Module):
         self.last_packed34: Optional[torch.Tensor] = None
         self._ws_tag = "g0"
         self._host_cache = None
+        self._side_streams = {}   # device -> stream of the asynchronous ids copy (see _host_ids_begin)
         self.debug_probes: Optional[Dict[str, torch.Tensor]] = None  # tests set {} to capture per-layer states
         self.use_gemm_workspace = True   # hand the GEMMs of a forward a split-K scratch (False: no GEMM slices K; tests)
 
@@ -456,17 +457,53 @@ class InternVLChatRewardModeling(nn.Module):
         """Token ids / mask as host numpy arrays: ONE device->host copy per forward (none for CPU tensors, none when the
         same unmodified tensors are passed again).  The reference does the same round trip with ``ids.tolist()``
         (moe_reward.py:242); everything the kernels need from the ids (row maps, lengths) is derived on the host."""
+        return self._host_ids_begin(input_ids, attention_mask)()
+
+    def _host_ids_begin(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]):
+        """Starts the device->host copy of the ids / mask and returns a function that waits for it and yields the numpy
+        arrays.  The copy runs on a SIDE stream behind an event recorded on the current stream now: it waits for whatever
+        the caller enqueued before the forward (the ids' producer among it) but not for what the forward enqueues next - the
+        vision tower needs no ids, so its launches go out first and the host's wait for the ids (which in a stream of
+        back-to-back batches is a wait for the previous batch's GPU work), its analysis of them and the uploads all hide
+        under vision-tower kernels (tools/step_bubble.py: a blocking ``ids.cpu()`` at the top of the forward left the GPU idle
+        for 0.7-0.8 ms of a 93 ms step)."""
         c = self._host_cache
         if (c is not None and c[0] is input_ids and c[1] == input_ids._version and c[2] is attention_mask
                 and (attention_mask is None or c[3] == attention_mask._version)):
-            return c[4], c[5]
-        ids = input_ids.detach().to("cpu").numpy()
-        am = None if attention_mask is None else attention_mask.detach().to("cpu").numpy().astype(bool)
-        # the cache holds the tensors themselves: an address-based key could match a NEW tensor that the allocator
-        # placed where a freed one used to live
-        self._host_cache = (input_ids, input_ids._version, attention_mask,
-                            None if attention_mask is None else attention_mask._version, ids, am)
-        return ids, am
+            return lambda: (c[4], c[5])
+
+        def remember(ids, am):
+            # the cache holds the tensors themselves: an address-based key could match a NEW tensor that the allocator
+            # placed where a freed one used to live
+            self._host_cache = (input_ids, input_ids._version, attention_mask,
+                                None if attention_mask is None else attention_mask._version, ids, am)
+            return ids, am
+
+        if not input_ids.is_cuda or (attention_mask is not None and not attention_mask.is_cuda):
+            return lambda: remember(input_ids.detach().to("cpu").numpy(),
+                                    None if attention_mask is None else attention_mask.detach().to("cpu").numpy().astype(bool))
+        dev = input_ids.device
+        with torch.cuda.device(dev):
+            side = self._side_streams.get(dev)
+            if side is None:
+                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            pin_ids = torch.empty(input_ids.shape, dtype=input_ids.dtype, pin_memory=True)
+            pin_am = None if attention_mask is None else torch.empty(attention_mask.shape, dtype=attention_mask.dtype, pin_memory=True)
+            done = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                pin_ids.copy_(input_ids.detach(), non_blocking=True)
+                if pin_am is not None:
+                    pin_am.copy_(attention_mask.detach(), non_blocking=True)
+                done.record(side)
+
+        def wait():
+            done.synchronize()
+            return remember(pin_ids.numpy(), None if pin_am is None else pin_am.numpy().astype(bool))
+
+        return wait
 
     def _analyse_ids(self, ids: np.ndarray, am: Optional[np.ndarray], n_tiles: int):
         if ids.ndim != 2:
@@ -529,6 +566,11 @@ class InternVLChatRewardModeling(nn.Module):
     # -- towers ----------------------------------------------------------------------------------
     def _vision_tower(self, d, pixel_values: torch.Tensor, hidden: torch.Tensor, img_rows: torch.Tensor):
         """patchify -> 24 x ViT layer -> pixel-shuffle + mlp1, scattered into the <IMG_CONTEXT> rows of ``hidden``."""
+        self._vision_tower_splice(self._vision_tower_launch(d, pixel_values), hidden, img_rows)
+
+    def _vision_tower_launch(self, d, pixel_values: torch.Tensor):
+        """Everything of the vision tower that needs no token ids: patchify -> 24 x ViT layer -> pixel-shuffle + LayerNorm +
+        first projector layer.  Returns what ``_vision_tower_splice`` needs."""
         dev = pixel_values.device
         vc = self.config.vision_config
         vm = self.model.vision_model
@@ -567,10 +609,16 @@ class InternVLChatRewardModeling(nn.Module):
         ops.layernorm(x, mlp1[0].weight, mlp1[0].bias, pl, mlp1[0].eps, rows=ntok, gather_grid=G)
         ph = self._buf("proj_h", ntok, mlp1[1].out_features, dev)
         ops.gemm(pl, mlp1[1].weight, ph, EPI_BIAS_GELU, bias=mlp1[1].bias)
+        return ph, tiles
+
+    def _vision_tower_splice(self, vit, hidden: torch.Tensor, img_rows: torch.Tensor):
+        """second projector layer, its rows written straight into the <IMG_CONTEXT> rows of ``hidden``
+        (modeling_internvl_chat.py:176-179)"""
+        ph, tiles = vit
+        mlp1 = self.model.mlp1
         ops.gemm(ph, mlp1[3].weight, hidden, EPI_BIAS, bias=mlp1[3].bias, out_rows=img_rows)
-        if probes is not None:
-            probes["vit_embeds"] = hidden[img_rows.long()].clone().view(tiles, -1, hidden.shape[1])
-        return x
+        if self.debug_probes is not None:
+            self.debug_probes["vit_embeds"] = hidden[img_rows.long()].clone().view(tiles, -1, hidden.shape[1])
 
     def _vit_layer(self, layer, x, h, qkv, f, cu, T):
         """One InternVisionEncoderLayer (modeling_intern_vit.py:283-295) in place on the packed rows ``x`` [tiles * T, dim];
@@ -683,14 +731,18 @@ class InternVLChatRewardModeling(nn.Module):
         return x
 
     # -- forward ---------------------------------------------------------------------------------
-    def _forward_group(self, d, tag: str, pixel_values, input_ids, attention_mask, outs, lo: int, probes_ok: bool):
-        """Scores the batch on the CURRENT stream of the model's device (outputs go to rows [lo, lo+B) of ``outs``)."""
+    def _forward_group(self, d, tag: str, pixel_values, host_ids, outs, lo: int, probes_ok: bool):
+        """Scores the batch on the CURRENT stream of the model's device (outputs go to rows [lo, lo+B) of ``outs``).
+        ``host_ids``: function returning the (ids, mask) numpy arrays (``_host_ids_begin``) - called only after the vision
+        tower's launches are out."""
         dev = pixel_values.device
         self._ws_tag = tag
         # split-K scratch of this forward's GEMMs (private to this model instance and to the stream the forward runs on;
         # ops keeps it per THREAD: another thread scoring with another model instance has its own)
         ops.set_gemm_workspace(self._buf("gemm_ws", 1, ops.gemm_workspace_bytes(), dev, dtype=torch.uint8)
                                if self.use_gemm_workspace else None)
+        vit = self._vision_tower_launch(d, pixel_values)     # (needs no ids: enqueued before the host waits for them)
+        input_ids, attention_mask = host_ids()
         info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])  # host arrays (see forward)
         B, total = info["B"], info["total"]
         lc = self.config.llm_config
@@ -703,7 +755,7 @@ class InternVLChatRewardModeling(nn.Module):
         img_rows, sel_rows = up(info["img_rows"]), up(info["sel_rows"])
         hidden = self._buf("llm_x", total, hdim, dev)
         ops.embed_gather(ids, self.model.language_model.model.tok_embeddings.weight, hidden, self.model.img_context_token_id)
-        self._vision_tower(d, pixel_values, hidden, img_rows)
+        self._vision_tower_splice(vit, hidden, img_rows)
         if self.debug_probes is not None and probes_ok:
             self.debug_probes["llm_embed"] = hidden.clone()
         trimmed = self.debug_probes is None
@@ -823,12 +875,12 @@ class InternVLChatRewardModeling(nn.Module):
         if self.config.pad_token_id is None and B != 1:   # moe_reward.py:218-219
             raise ValueError("Cannot handle batch sizes > 1 if no padding token is defined.")
         outs = self._alloc_outputs(B, dev)
-        ids_h, am_h = self._host_ids(input_ids, attention_mask)
         try:
             # the model's device becomes the current device for the whole forward (allocations, events, the library's
             # per-device kernel attributes), whatever the caller's current device is: model.cuda(1) works like the reference
             with torch.cuda.device(dev):
-                self._forward_group(d, "g0", pixel_values, ids_h, am_h, outs, 0, True)
+                host_ids = self._host_ids_begin(input_ids, attention_mask)
+                self._forward_group(d, "g0", pixel_values, host_ids, outs, 0, True)
         finally:   # the split-K scratch is this thread's default in ops: do not leave it behind for other gemm callers
             ops.set_gemm_workspace(None)
         self.last_packed34 = outs.pop("packed34")
