@@ -353,6 +353,48 @@ def test_attention(cuda, attn_variant, D, H, G, causal, lens):
     assert_close_bf16(out, ref, 2, atol=0.02, what="attention")
 
 
+@pytest.mark.parametrize("D,causal,L", [(64, False, 1025), (64, False, 1024), (64, True, 700), (128, True, 2186), (128, False, 577)])
+@pytest.mark.parametrize("ramp", [0.6, 0.12, -0.6])
+def test_attention_rising_scores_exercise_the_offset_raise(cuda, attn_variant, D, causal, L, ramp):
+    """The round-3 kernel keeps an integer softmax offset per query and raises it only when a lane's partial row sum reaches
+    2^20 - on bounded random data that branch fires for the first unit only (offset from 'none' to the first maximum), so
+    random tests say nothing about a raise in mid-sequence, where O, l and the exponentials in flight all have to move to the
+    new offset exactly once.  Here the scores RISE along the keys (ramp 0.6 / 0.12 log2 units per key plus noise: a raise every
+    ~30 / ~150 keys, each by a few binades, so what was accumulated before stays significant after it), or fall (-0.6: never a
+    raise, the first keys dominate).  Against the fp32 reference, same bounds as test_attention."""
+    from mj_video_amd import ops
+    if not causal and L > 600 and ramp > 0.5:
+        # (every query sees the top of the ramp: raw scores of +-3 400, where one bf16 ulp of the reference's OWN score rounding is
+        # 2 in the exponent - all five kernel choices land at the same 7e-3 from the reference there; the ramp is halved instead)
+        ramp = 0.3
+    H, G = 4, 2 if D == 128 else 1
+    KVH = H // G
+    g = torch.Generator().manual_seed(41)
+    scale = D ** -0.5
+    mode = 1 if causal else 0
+    # q = a fixed direction u (+ noise), k_j = (ramp * j / (scale * log2 e)) * u / |u|^2 (+ noise): q . k_j * scale * log2 e ~ ramp * j
+    u = torch.randn(D, generator=g)
+    u = u / u.norm()
+    qn = 4.0
+    q = (qn * u + 0.3 * torch.randn(L, H, D, generator=g)).to(BF)
+    step = ramp / (scale * math.log2(math.e) * qn)
+    j = torch.arange(L, dtype=torch.float32).view(L, 1, 1)
+    k = (step * j * u + 0.3 * torch.randn(L, KVH, D, generator=g)).to(BF)
+    v = torch.randn(L, KVH, D, generator=g).to(BF)
+    q2, k2, v2 = q.reshape(L, H * D), k.reshape(L, KVH * D), v.reshape(L, KVH * D)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    out = torch.full((L, H * D), float("nan"), dtype=BF, device=cuda)
+    ops.attention(q2.to(cuda), k2.to(cuda), v2.to(cuda), out, cu.to(cuda), L, H, G, D, causal, scale, mode)
+    ref = attn_reference(q2, k2, v2, [L], H, G, D, causal, scale, mode)
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    rel = (o - ref.float()).norm() / ref.float().norm()
+    # (large raw scores: a one-ulp flip of the reference's own bf16 score rounding moves single probabilities by several per
+    # cent - tools/fuzz_kernels.py - so the cell bound is relative to the largest output)
+    assert rel.item() < 6e-3, f"relative L2 error {rel.item():.3e}"
+    assert (o - ref.float()).abs().max().item() < 0.08 * ref.float().abs().max().item() + 0.02
+
+
 def test_attention_exact_selection(cuda, attn_variant):
     """one-hot softmax (a huge score on one key): output must equal that key's V row bit for bit; checks the
     key<->value pairing of the transposed LDS reads and the causal/ragged masks"""
