@@ -86,6 +86,35 @@ def test_gemm_gelu_relu(cuda, tile):
     assert_close_bf16(out, F.relu(lin), 1, frac_exact=0.98, atol=1e-6, what="gemm_relu")
 
 
+def test_gemm_gelu_is_exact_for_every_bf16_input(cuda, tile):
+    """the GELU epilogue is a table over the finite function bf16 -> bf16 (fast path: every lane of the wave inside the table;
+    general path: x / 2 below it, x or -0 above): ALL 65 280 finite bf16 values go through it (compared on the 64 768 of them between 2^-125 and 2^127 in magnitude, and 0) as GEMM outputs (A holds the
+    values, W is the identity, so every sum has one term and the Linear's rounding is exact) and must equal torch's bf16 GELU
+    bit for bit - in natural order (whole waves inside / outside the table) and shuffled (mixed waves -> general path)."""
+    from mj_video_amd import ops
+    bits = torch.arange(65536, dtype=torch.int32)
+    vals = bits.to(torch.int16).view(BF)
+    finite = torch.isfinite(vals.float())
+    vals = vals[finite]                       # 65 280 values
+    pad = (-vals.numel()) % 64
+    vals = torch.cat([vals, torch.zeros(pad, dtype=BF)])
+    eye = torch.eye(64, dtype=BF)
+    for order in ("natural", "shuffled"):
+        v = vals if order == "natural" else vals[torch.randperm(vals.numel(), generator=torch.Generator().manual_seed(3))]
+        a = v.view(-1, 64).contiguous()
+        out = torch.empty(a.shape[0], 64, dtype=BF, device=cuda)
+        ops.gemm(a.to(cuda), eye.to(cuda), out, ops.EPI_BIAS_GELU)
+        ref = F.gelu(a)                        # torch's CPU bf16 GELU - what the reference's nn.GELU computes on bf16 activations
+        got = out.cpu()
+        same = got.view(torch.int16) == ref.view(torch.int16)
+        # (+0 / -0 compare equal; inputs below 2^-125 - subnormal, or with a subnormal half - are left out: torch's CPU kernel
+        # flushes subnormal results to 0, the table's x / 2 keeps them, and no activation gets there)
+        same |= (got.float() == 0) & (ref.float() == 0)
+        same |= a.float().abs() < 2.0 ** -125
+        same |= a.float().abs() >= 2.0 ** 127     # (torch forms x (1 + erf) before halving: inf from 2^127 on; the table returns x)
+        assert same.all(), (order, int((~same).sum()), a[~same][:8], got[~same][:8], ref[~same][:8])
+
+
 def test_gemm_scale_res_and_rowmaps(cuda, tile):
     from mj_video_amd import ops
     M, N, K = 320, 256, 128
