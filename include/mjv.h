@@ -19,6 +19,10 @@
  *     the measurement switches of earlier ABI versions live in the separate bench build (include/mjv_bench.h);
  *   - return value 0 = ok, negative = error (MJV_E_*); `mjv_last_error()` gives a thread-local message.
  *   - rounding points follow the reference's bf16 eager path (bf16 result after every torch op).
+ *
+ * ABI 5 adds the MX-fp8 operand format for the GEMMs (BASELINE configs[4]; opt-in, the default path
+ * is bf16 as before): the `*_format` / `*_scales` fields at the END of the GEMM descriptor - all zero = bf16 everywhere -,
+ * mjv_quantize_mxfp8, mjv_layernorm_mxfp8, mjv_rmsnorm_mxfp8.
  */
 #ifndef MJV_H_
 #define MJV_H_
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJV_ABI_VERSION 4
+#define MJV_ABI_VERSION 5
 
 enum {
   MJV_OK = 0,
@@ -39,6 +43,26 @@ enum {
 };
 
 typedef uint16_t mjv_bf16;
+
+/* ---------------------------------------------------------------------------------------------
+ * MXFP8 operand format (OCP Microscaling v1.0 "MXFP8 E4M3": 32-element blocks along K with one shared power-of-two
+ * scale; the format gfx950's v_mfma_scale_f32_16x16x128_f8f6f4 consumes).  The reference has no fp8 path (its README
+ * names only the 2B bf16 checkpoint; BASELINE configs[4] asks for an fp8 MFMA weight path): this is a definition, pinned by
+ * oracle/ref_fp8.py, not a restatement.
+ *   elements : uint8 OCP e4m3fn, row-major [rows][ld] (K contiguous), K % 128 == 0, ld % 16 == 0
+ *   scales   : uint8 e8m0 (value 2^(b - 127)), one per (row, 32-element block).  For a block of bf16 values with largest
+ *              magnitude amax (bf16 bits u = E:8 | m:7):  b = max(1, E - 8 + (m > 0x60));  the smallest power of two with
+ *              amax / 2^(b-127) <= 448, so no element saturates;  element = e4m3_rne(x / 2^(b-127)).
+ *   scale layout ("lane layout" of the MFMA's scale operand): byte offset of (row, block kb of K-tile kt = k / 128)
+ *              = ((kt * groups + row / 64) * 256) + (row % 16) * 16 + kb * 4 + (row / 16) % 4,   groups = ceil(rows / 64);
+ *              i.e. per K-tile and 64-row group one 256-byte record whose dword [row % 16][kb] holds the four 16-row
+ *              fragments' bytes - the dword a lane hands to the MFMA with op_sel = fragment.  mjv_mxfp8_scale_bytes().
+ * ------------------------------------------------------------------------------------------- */
+enum mjv_format { MJV_FMT_BF16 = 0, MJV_FMT_MXFP8 = 1 };
+int64_t mjv_mxfp8_scale_bytes(int64_t rows, int64_t cols);
+/* bf16 [rows][ldx] -> MXFP8 elements [rows][ldy] + scales (weights once at load; tests).  cols % 128 == 0. */
+int mjv_quantize_mxfp8(const uint16_t* x, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* scales, int32_t rows, int32_t cols,
+                       void* stream);
 
 int mjv_abi_version(void);
 const char* mjv_last_error(void);
@@ -97,6 +121,17 @@ typedef struct mjv_gemm_desc {
   mjv_bf16 *rope_q, *rope_k;             /* outputs */
   int64_t rope_ldq, rope_ldk;
   int32_t rope_group;                    /* q heads per kv head */
+  /* ---- ABI 5: operand / output formats (enum mjv_format; all zero = bf16 everywhere, the ABI-4 behaviour) ----
+   * a_format == w_format == MJV_FMT_MXFP8: A and W point to e4m3 bytes (lda / ldw in BYTES = elements), a_scales / w_scales
+   * to their scale records (layout above; groups = ceil(M / 64) and ceil(N / 64)); K % 128 == 0; the product of the
+   * dequantised operands is accumulated in fp32 by v_mfma_scale_f32_16x16x128_f8f6f4 and the epilogue is the bf16 one.
+   * Epilogues: BIAS, BIAS_GELU, BIAS_RELU, SCALE_RES, SILU_MUL (plain output rows only; no ROPE_QKV).
+   * c_format == MJV_FMT_MXFP8 (BIAS, BIAS_GELU, BIAS_RELU, SILU_MUL): the epilogue's bf16 result is block-quantised on
+   * the way out - C points to e4m3 bytes (ldc in bytes), c_scales to its scale records (groups = ceil(M / 64)); output
+   * width (N, or N / 2 for SILU_MUL) % 128 == 0.  Bit-identical to the bf16 output followed by mjv_quantize_mxfp8. */
+  int32_t a_format, w_format, c_format;
+  const uint8_t *a_scales, *w_scales;
+  uint8_t* c_scales;
 } mjv_gemm_desc;
 
 /* a workspace of this size is enough for every problem shape (256 partial 256x256 fp32 tiles = 64 MiB) */
@@ -149,6 +184,13 @@ int mjv_layernorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy,
  * row_index (optional, device) gathers input rows: y[i] = norm(x[row_index[i]]). */
 int mjv_rmsnorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy, const mjv_bf16* w,
                      const int32_t* row_index, int32_t rows, int32_t dim, float eps, void* stream);
+
+/* the same two norms with an MXFP8 output (elements y [rows][ldy] bytes + scale records): bf16(norm(x)) exactly as above,
+ * then block-quantised - what the fp8 FFN GEMMs (fc1, w1|w3) read.  dim % 128 == 0.  No gathers. */
+int mjv_layernorm_mxfp8(const mjv_bf16* x, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* y_scales, const mjv_bf16* gamma,
+                        const mjv_bf16* beta, int32_t rows, int32_t dim, float eps, void* stream);
+int mjv_rmsnorm_mxfp8(const mjv_bf16* x, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* y_scales, const mjv_bf16* w,
+                      int32_t rows, int32_t dim, float eps, void* stream);
 
 /* GQA de-interleave + rotary embedding (modeling_internlm2.py:361-381,233-247):
  * qkv [rows][kv_heads * (group + 2) * 128] -> q [rows][kv_heads*group*128], k [rows][kv_heads*128], both rotated

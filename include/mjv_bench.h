@@ -16,10 +16,13 @@ extern "C" {
  * 4100 + s caps the slices per tile at s (1..8); 4300 + n sets the fewest K-tiles per 256-tile slice; 2000 + g forces the
  * group-M of the tile order (2000 = per shape); 6000 + m = largest M the skinny kernel takes (6000 = never);
  * 1000 / 1003 / 1004 / 1006 select the 256-tile kernel's variants (1003: no epilogue, 1004: no global stores - wrong results;
- * 1006: s_memtime stamps of wave 0 to the stamp buffer). */
+ * 1006: s_memtime stamps of wave 0 to the stamp buffer; 1008: the persistent kernel with shader-clock / 100 MHz stamps around
+ * every tile's main loop, summed per workgroup into slots 2 / 6 of its 8 x uint64 and the tile count into slot 7 - zero the
+ * buffer first; 1009: never the persistent form). */
 int mjv_bench_gemm_set(int32_t code);
 /* 1006: wave 0 of every workgroup writes 8 x uint64 {start stamp, prologue, main loop, epilogue pass A, pass B, total
- * cycles} to this device buffer; NULL = off */
+ * cycles, main loop in 100 MHz ticks (s_memrealtime)} to this device buffer; NULL = off.  Clock held in the main loop =
+ * slot 2 / slot 6 x 100 MHz (MI355X_MICROARCH.md "DVFS give-back" item 6). */
 int mjv_bench_gemm_stamp_buffer(void* device_buffer);
 /* attention: 0 = production; on the two production shapes of the round-2 kernel (desc.kernel = 5) 1 = K/V staged once,
  * 2 = softmax removed, 3 = MFMAs removed - wrong results. */

@@ -22,7 +22,8 @@ class MjvLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4  # MJV_ABI_VERSION of include/mjv.h
+ABI_VERSION = 5  # MJV_ABI_VERSION of include/mjv.h
+FMT_BF16, FMT_MXFP8 = 0, 1   # enum mjv_format
 
 
 class GemmDesc(C.Structure):
@@ -33,7 +34,10 @@ class GemmDesc(C.Structure):
                 ("out_pad", C.c_int32), ("out_rows", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_int64), ("tile", C.c_int32), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("rope_pos", C.c_void_p), ("rope_q", C.c_void_p), ("rope_k", C.c_void_p), ("rope_ldq", C.c_int64),
-                ("rope_ldk", C.c_int64), ("rope_group", C.c_int32)]
+                ("rope_ldk", C.c_int64), ("rope_group", C.c_int32),
+                # ABI 5: operand / output formats (all zero = bf16)
+                ("a_format", C.c_int32), ("w_format", C.c_int32), ("c_format", C.c_int32),
+                ("a_scales", C.c_void_p), ("w_scales", C.c_void_p), ("c_scales", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -69,6 +73,10 @@ SYMBOLS = {
     "mjv_attention_bf16": (C.c_int, [C.POINTER(AttnDesc), _VP]),
     "mjv_layernorm_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, _F, _I32, _VP]),
     "mjv_rmsnorm_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, _F, _VP]),
+    "mjv_mxfp8_scale_bytes": (C.c_int64, [_I64, _I64]),
+    "mjv_quantize_mxfp8": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _I32, _I32, _VP]),
+    "mjv_layernorm_mxfp8": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _I32, _I32, _F, _VP]),
+    "mjv_rmsnorm_mxfp8": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, _F, _VP]),
     "mjv_rope_split_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "mjv_patchify_bf16": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _VP]),
     "mjv_cls_rows_bf16": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _I32, _I32, _VP]),

@@ -979,7 +979,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   // fragments) that in reality wait for the youngest operations in the queue - the DMA just issued
   __builtin_amdgcn_s_waitcnt(0x0F70);
 #ifdef MJV_ATTN_STAMPS
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+  unsigned long long st_rt0;   // the 100 MHz counter beside the shader clock: clock held in the tile loop = d[13] / d[15] x 100 MHz
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev), "=s"(st_rt0)::"memory");
   const unsigned long long st_begin = st_prev;
 #endif
   issue(0, 0);
@@ -1018,6 +1019,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   for (; kt < n_tiles; ++kt) step(kt, std::false_type{}, general);
 
 #ifdef MJV_ATTN_STAMPS
+  unsigned long long st_rt1;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1)::"memory");
   if (g_stamp_out && lane == 0) {
     unsigned long long* d = g_stamp_out + ((long)blockIdx.x * NW + wave) * 16;
 #pragma unroll
@@ -1025,6 +1028,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     d[12] = (unsigned long long)n_tiles;
     d[13] = st_prev - st_begin;
     d[14] = (unsigned long long)((hasA ? 1 : 0) + ((hasB || (NSUB == 1 && hasA)) ? 1 : 0) + (cls_block ? 4 : 0));
+    d[15] = st_rt1 - st_rt0;
   }
 #endif
   if (cls_block) {   // workgroup-uniform: merge wave 1's state (the second key half of every tile) into wave 0's

@@ -593,6 +593,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       return 0ull;
     }
   };
+  // (same build: the 100 MHz constant-rate counter beside the shader-clock one around the main loop -> the clock the chip
+  // holds inside it = d[2] / d[6] x 100 MHz, MI355X_MICROARCH.md "DVFS give-back" item 6)
+  auto stamp_rt = [&]() -> unsigned long long {
+    if constexpr (VAR == 6) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      return t;
+    } else {
+      return 0ull;
+    }
+  };
   const unsigned long long t_start = stamp();
   // bias of this lane's 4 x 4 output columns: requested before the first DMA (oldest in the in-order vmcnt queue, so the
   // counted waits below mean what they meant), used in pass A - loaded there, each of the four loads was followed by its
@@ -651,6 +664,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   MJV_BARRIER();
   if (wr == 1) MJV_BARRIER();  // stagger the second M-group by one barrier
   const unsigned long long t_pro = stamp();
+  const unsigned long long r_pro = stamp_rt();
 
   bf16x8 af[4][2], wf[2][2][2];  // af[i][kk]; wf[ns][j][kk]
 
@@ -714,6 +728,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   // flight time pass A is there to cover
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
   const unsigned long long t_main = stamp();
+  const unsigned long long r_main = stamp_rt();
 #undef MJV_LOAD_A
 #undef MJV_LOAD_W
 #undef MJV_MFMA
@@ -964,7 +979,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (p.ws && tid == 0) {
       unsigned long long* d = (unsigned long long*)p.ws + (long)blockIdx.x * 8;
       d[0] = t_start; d[1] = t_pro - t_start; d[2] = t_main - t_pro; d[3] = t_passA - t_main; d[4] = t_end - t_passA;
-      d[5] = t_end - t_start;
+      d[5] = t_end - t_start; d[6] = r_main - r_pro;
     }
   }
 }
@@ -1141,6 +1156,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
   MJV_MFMA_K(MS, NS, 1)                                \
   __builtin_amdgcn_s_setprio(0);
 
+#ifdef MJV_BENCH   // bench build, variant 1008: shader-clock and 100 MHz stamps around this tile's main loop (wave 0)
+    unsigned long long bt0 = 0, br0 = 0;
+    if (p.ws) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(bt0), "=s"(br0)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     for (int t = 0; t < nk; ++t) {   // (the two-phase loop of gemm256_kernel, unchanged)
       const char* abase = smem + ((t & 1) * 4 + a_half) * HALF_BYTES;
       const char* wbase = smem + ((t & 1) * 4 + w_half) * HALF_BYTES;
@@ -1167,6 +1190,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     }
     if (wr == 0) MJV_BARRIER();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) in the form the compiler's wait-count pass reads (see gemm256_kernel)
+#ifdef MJV_BENCH
+    if (p.ws) {
+      unsigned long long bt1, br1;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(bt1), "=s"(br1)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (tid == 0) {
+        unsigned long long* d = (unsigned long long*)p.ws + (long)blockIdx.x * 8;
+        d[2] += bt1 - bt0; d[6] += br1 - br0; d[7] += 1;
+      }
+    }
+#endif
 #undef MJV_LOAD_A
 #undef MJV_LOAD_W
 #undef MJV_MFMA
@@ -1394,6 +1429,7 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
                         nk >= 4 && (nk & 1) == 0;
 #ifdef MJV_BENCH
       if (MJV_TUNE(variant) == 9) persistent = false;   // A/B: the one-tile-per-workgroup kernel
+      a.ws = MJV_TUNE(variant) == 8 ? (float*)MJV_TUNE(stamp_buffer) : nullptr;   // 1008: main-loop clock stamps (persistent form)
 #endif
       if constexpr (EPI != MJV_EPI_ROPE_QKV) {
         if (persistent) {
@@ -1453,6 +1489,8 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   MJV_REQUIRE(d && d->A && d->W && d->C, "gemm: null pointer");
   MJV_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
   MJV_REQUIRE(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256, "gemm: tile %d not in {0, 64, 128, 256}", d->tile);
+  if (d->a_format != MJV_FMT_BF16 || d->w_format != MJV_FMT_BF16) return mjv_gemm_mxfp8_dispatch(d, stream);   // gemm_fp8.hip
+  MJV_REQUIRE(d->c_format == MJV_FMT_BF16, "gemm: an MXFP8 output needs MXFP8 operands");
   const int force_tile = d->tile;
   MJV_REQUIRE(d->K % 64 == 0, "gemm: K=%d must be a multiple of 64", d->K);
   MJV_REQUIRE(d->N % 8 == 0, "gemm: N=%d must be a multiple of 8", d->N);

@@ -63,6 +63,9 @@ void mjv_set_error(const char* fmt, ...);
 int mjv_check_launch(const char* what);
 int mjv_device_cus();   // multiProcessorCount of the current device (cached per device)
 
+// MXFP8 operands (gemm_fp8.hip); mjv_gemm_bf16 hands descriptors that name them over
+int mjv_gemm_mxfp8_dispatch(const mjv_gemm_desc* d, void* stream);
+
 // profiler hooks (capi.cpp)
 struct MjvProfScope {
   MjvProfScope(const char* tag, hipStream_t s, double flops, double bytes);

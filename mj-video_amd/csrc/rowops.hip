@@ -1,6 +1,7 @@
 // HBM-bound row kernels: LayerNorm (+pixel-shuffle gather), RMSNorm (+row gather), RoPE/GQA split,
 // patchify (im2col), CLS rows, token-embedding gather.  One 64-lane wave per row, 16-byte accesses.
 #include "mjv_common.h"
+#include "mx8.h"
 
 namespace {
 
@@ -13,10 +14,13 @@ constexpr int MAX_IT = 8;         // 8 chunks of 512 elements -> rows up to 4096
 // modeling_internvl_chat.py:228-242): out token (tile, a2, b2) <- rows (2a2,2b2) (2a2,2b2+1) (2a2+1,2b2) (2a2+1,2b2+1).
 // IT = chunks of 512 elements a lane group covers (row width <= 512 * IT): the narrower instantiations keep fewer values
 // in registers, so more rows are in flight per CU.
-template <int IT>
+// MX8: the bf16 result is block-quantised on the way out (y = e4m3 bytes, ldy in bytes, ys = scale records; include/mjv.h
+// "MXFP8 operand format"): the input of the fp8 fc1 GEMM.  A lane's 8 columns are a quarter of a 32-element block.
+template <int IT, bool MX8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ y, long ldy,
                                                         const u16* __restrict__ gamma, const u16* __restrict__ beta,
-                                                        int rows, int dim, float eps, int grid) {
+                                                        int rows, int dim, float eps, int grid, uint8_t* __restrict__ ys = nullptr,
+                                                        long groups = 0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -75,7 +79,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
       unpack8(*(const u32x4*)(beta + c), b);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (v[it][j] - mean) * rstd * g[j] + b[j];
-      *(u32x4*)(y + (long)row * ldy + c) = pack8(o);
+      if constexpr (MX8) {
+        unsigned sb;
+        const u32x2 q = mx8_quantize_quad(pack8(o), sb);   // (dim % 128 == 0: whole quads are inside the row)
+        *(u32x2*)((uint8_t*)y + (long)row * ldy + c) = q;
+        if ((lane & 3) == 0) ys[mx8_scale_offset(row, c, groups)] = (uint8_t)sb;
+      } else {
+        *(u32x4*)(y + (long)row * ldy + c) = pack8(o);
+      }
     }
   }
 }
@@ -84,10 +95,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
 // modeling_internlm2.py:138-143: h = bf16(x32 * rsqrt(mean(x32^2) + eps)); y = bf16(w * h)
 // PARTS > 0 (bench build only, the A/B of DESIGN "Norm fusion"): the row's sum of squares arrives as PARTS per-n-tile partial
 // sums from the producing GEMM's epilogue ([rows][PARTS] fp32, summed here in tile order) instead of being reduced in here
-template <int IT, int PARTS = 0>
+template <int IT, int PARTS = 0, bool MX8 = false>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ y, long ldy,
                                                       const u16* __restrict__ w, const int* __restrict__ row_index,
-                                                      int rows, int dim, float eps, const float* __restrict__ partials = nullptr) {
+                                                      int rows, int dim, float eps, const float* __restrict__ partials = nullptr,
+                                                      uint8_t* __restrict__ ys = nullptr, long groups = 0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -121,7 +133,14 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* __restrict__ x,
       unpack8(*(const u32x4*)(w + c), g);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = g[j] * rbf(v[it][j] * rstd);
-      *(u32x4*)(y + (long)row * ldy + c) = pack8(o);
+      if constexpr (MX8) {   // (see layernorm_kernel: the input of the fp8 w1|w3 GEMM)
+        unsigned sb;
+        const u32x2 q = mx8_quantize_quad(pack8(o), sb);
+        *(u32x2*)((uint8_t*)y + (long)row * ldy + c) = q;
+        if ((lane & 3) == 0) ys[mx8_scale_offset(row, c, groups)] = (uint8_t)sb;
+      } else {
+        *(u32x4*)(y + (long)row * ldy + c) = pack8(o);
+      }
     }
   }
 }
@@ -236,6 +255,44 @@ extern "C" int mjv_rmsnorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int
   else
     hipLaunchKernelGGL(rmsnorm_kernel<MAX_IT>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w, row_index, rows, dim, eps);
   return mjv_check_launch("rmsnorm");
+}
+
+extern "C" int mjv_layernorm_mxfp8(const mjv_bf16* x, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* y_scales, const mjv_bf16* gamma,
+                                   const mjv_bf16* beta, int32_t rows, int32_t dim, float eps, void* stream) {
+  MJV_REQUIRE(x && y && y_scales && gamma && beta, "layernorm_mxfp8: null pointer");
+  MJV_REQUIRE(rows > 0 && dim > 0 && dim % 128 == 0 && dim <= 512 * MAX_IT, "layernorm_mxfp8: dim %d unsupported", dim);
+  MJV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && (uintptr_t)y % 8 == 0, "layernorm_mxfp8: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  MjvProfScope ps("layernorm_mxfp8", s, 0, 3.03 * rows * (double)dim);
+  const dim3 grid((rows + WAVES - 1) / WAVES);
+  const long groups = (rows + 63) / 64;
+  if (dim <= 1024)
+    hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, s, x, (long)ldx, (u16*)y, (long)ldy, gamma, beta, rows, dim, eps, 0, y_scales, groups);
+  else if (dim <= 2048)
+    hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, s, x, (long)ldx, (u16*)y, (long)ldy, gamma, beta, rows, dim, eps, 0, y_scales, groups);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<MAX_IT, true>), grid, dim3(256), 0, s, x, (long)ldx, (u16*)y, (long)ldy, gamma, beta, rows, dim, eps, 0, y_scales, groups);
+  return mjv_check_launch("layernorm_mxfp8");
+}
+
+extern "C" int mjv_rmsnorm_mxfp8(const mjv_bf16* x, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* y_scales, const mjv_bf16* w,
+                                 int32_t rows, int32_t dim, float eps, void* stream) {
+  MJV_REQUIRE(x && y && y_scales && w, "rmsnorm_mxfp8: null pointer");
+  MJV_REQUIRE(rows > 0 && dim > 0 && dim % 128 == 0 && dim <= 512 * MAX_IT, "rmsnorm_mxfp8: dim %d unsupported", dim);
+  MJV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && (uintptr_t)y % 8 == 0, "rmsnorm_mxfp8: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  MjvProfScope ps("rmsnorm_mxfp8", s, 0, 3.03 * rows * (double)dim);
+  const dim3 grid((rows + WAVES - 1) / WAVES);
+  const long groups = (rows + 63) / 64;
+  const int* no_index = nullptr;
+  const float* no_parts = nullptr;
+  if (dim <= 1024)
+    hipLaunchKernelGGL((rmsnorm_kernel<2, 0, true>), grid, dim3(256), 0, s, x, (long)ldx, (u16*)y, (long)ldy, w, no_index, rows, dim, eps, no_parts, y_scales, groups);
+  else if (dim <= 2048)
+    hipLaunchKernelGGL((rmsnorm_kernel<4, 0, true>), grid, dim3(256), 0, s, x, (long)ldx, (u16*)y, (long)ldy, w, no_index, rows, dim, eps, no_parts, y_scales, groups);
+  else
+    hipLaunchKernelGGL((rmsnorm_kernel<MAX_IT, 0, true>), grid, dim3(256), 0, s, x, (long)ldx, (u16*)y, (long)ldy, w, no_index, rows, dim, eps, no_parts, y_scales, groups);
+  return mjv_check_launch("rmsnorm_mxfp8");
 }
 
 #ifdef MJV_BENCH

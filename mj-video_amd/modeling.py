@@ -336,6 +336,11 @@ class InternVLChatRewardModeling(nn.Module):
         self._side_streams = {}   # device -> stream of the asynchronous ids copy (see _host_ids_begin)
         self.debug_probes: Optional[Dict[str, torch.Tensor]] = None  # tests set {} to capture per-layer states
         self.use_gemm_workspace = True   # hand the GEMMs of a forward a split-K scratch (False: no GEMM slices K; tests)
+        # "bf16" (default: the reference's arithmetic) or "mxfp8": the five FFN Linears of both towers (fc1 / fc2, w1 | w3 / w2 -
+        # two thirds of the flops) run on MXFP8 operands (include/mjv.h; SURVEY.md §8(f)4, BASELINE configs[4]); weights are
+        # quantised once in _prepare, activations in the producing kernel (norm / GELU / SiLU-mul epilogue).  Not a drop-in for
+        # the reference's bf16 numbers: held to oracle/ref_fp8.py and reported with its own tolerance.
+        self.ffn_format = "bf16"
 
     # -- construction helpers -------------------------------------------------------------------
     @classmethod
@@ -350,9 +355,22 @@ class InternVLChatRewardModeling(nn.Module):
             torch.set_default_dtype(prev)
 
     # -- derived (pre-arranged) weights ----------------------------------------------------------
+    def set_ffn_format(self, fmt: str) -> "InternVLChatRewardModeling":
+        """"bf16" or "mxfp8" (see ``ffn_format``); takes effect at the next forward (weights are re-prepared)."""
+        if fmt not in ("bf16", "mxfp8"):
+            raise ValueError(f"ffn_format {fmt!r} not in ('bf16', 'mxfp8')")
+        if fmt == "mxfp8":
+            vc, lc = self.config.vision_config, self.config.llm_config
+            for nm, k in (("vision hidden_size", vc.hidden_size), ("vision intermediate_size", vc.intermediate_size),
+                          ("llm hidden_size", lc.hidden_size), ("llm intermediate_size", lc.intermediate_size)):
+                if k % 128:
+                    raise ValueError(f"mxfp8 FFN path: {nm} = {k} must be a multiple of 128 (the MFMA's K)")
+        self.ffn_format = fmt
+        return self
+
     def _signature(self):
         ps = list(self.parameters())
-        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps) + (self.ffn_format,)
 
     def _prepare(self, device):
         """One-time weight layout conversion (redone if any parameter storage/version changed):
@@ -384,6 +402,11 @@ class InternVLChatRewardModeling(nn.Module):
                 raise NotImplementedError("intermediate_size must be a multiple of 16")
             w13.append(torch.stack([w1.view(ff // 16, 16, h), w3.view(ff // 16, 16, h)], dim=1).reshape(2 * ff, h).contiguous())
         d["w13"] = w13
+        if self.ffn_format == "mxfp8":   # the FFN weights as MXFP8 (elements + block scales), quantised once
+            d["fc1_8"] = [ops.quantize_mxfp8(l.mlp.fc1.weight) for l in self.model.vision_model.encoder.layers]
+            d["fc2_8"] = [ops.quantize_mxfp8(l.mlp.fc2.weight) for l in self.model.vision_model.encoder.layers]
+            d["w13_8"] = [ops.quantize_mxfp8(w) for w in w13]
+            d["w2_8"] = [ops.quantize_mxfp8(l.feed_forward.w2.weight) for l in self.model.language_model.model.layers]
         offs, idx = [0], []
         for _, crit in self.aspect2criteria.items():
             idx += list(crit)
@@ -451,6 +474,12 @@ class InternVLChatRewardModeling(nn.Module):
             t = torch.empty(need, dtype=dtype, device=device)
             self._ws[name] = t
         return t[:need].view(rows, cols)
+
+    def _buf8(self, name: str, rows: int, cols: int, device) -> "ops.MX8":
+        """an MXFP8 scratch matrix of exactly ``rows`` rows (its scale records are laid out for that row count)"""
+        data = self._buf(name, rows, cols, device, dtype=torch.uint8)
+        scales = self._buf(name + ":s", 1, ops.mxfp8_scale_bytes(rows, cols), device, dtype=torch.uint8).view(-1)
+        return ops.MX8(data, scales)
 
     # -- host-side analysis of the token ids (the reference does this with ids.tolist(), moe_reward.py:242)
     def _host_ids(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]):
@@ -600,7 +629,7 @@ class InternVLChatRewardModeling(nn.Module):
             cu = torch.arange(0, (tiles + 1) * T, T, dtype=torch.int32, device=dev)
             self._ws[key] = cu
         for li, layer in enumerate(vm.encoder.layers):
-            self._vit_layer(layer, x, h, qkv, f, cu, T)
+            self._vit_layer(layer, x, h, qkv, f, cu, T, li)
             if probes is not None:
                 probes[f"vit_layer{li}"] = x.clone().view(tiles, T, dim)
         mlp1 = self.model.mlp1
@@ -620,9 +649,10 @@ class InternVLChatRewardModeling(nn.Module):
         if self.debug_probes is not None:
             self.debug_probes["vit_embeds"] = hidden[img_rows.long()].clone().view(tiles, -1, hidden.shape[1])
 
-    def _vit_layer(self, layer, x, h, qkv, f, cu, T):
+    def _vit_layer(self, layer, x, h, qkv, f, cu, T, li: int = -1):
         """One InternVisionEncoderLayer (modeling_intern_vit.py:283-295) in place on the packed rows ``x`` [tiles * T, dim];
-        ``h`` / ``qkv`` / ``f`` are scratch buffers of [rows, dim] / [rows, 3 dim] / [rows, intermediate]."""
+        ``h`` / ``qkv`` / ``f`` are scratch buffers of [rows, dim] / [rows, 3 dim] / [rows, intermediate].  ``li``: the layer's
+        index (the mxfp8 FFN path looks its quantised weights up by it)."""
         vc = self.config.vision_config
         dim, H = vc.hidden_size, vc.num_attention_heads
         scale = (dim // H) ** -0.5
@@ -630,6 +660,16 @@ class InternVLChatRewardModeling(nn.Module):
         ops.gemm(h, layer.attn.qkv.weight, qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
         ops.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], h, cu, T, H, 1, 64, False, scale, 0)
         ops.gemm(h, layer.attn.proj.weight, x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
+        if self.ffn_format == "mxfp8":
+            # norm2 -> fc1 (+GELU) -> fc2 on MXFP8 operands: the norm and the GELU epilogue write e4m3 + block scales
+            d = self._derived
+            rows, dev = x.shape[0], x.device
+            h8 = self._buf8("vit_h8", rows, dim, dev)
+            f8 = self._buf8("vit_f8", rows, vc.intermediate_size, dev)
+            ops.layernorm_mxfp8(x, layer.norm2.weight, layer.norm2.bias, h8, vc.layer_norm_eps)
+            ops.gemm(h8, d["fc1_8"][li], f8, EPI_BIAS_GELU, bias=layer.mlp.fc1.bias)
+            ops.gemm(f8, d["fc2_8"][li], x, EPI_SCALE_RES, bias=layer.mlp.fc2.bias, scale=layer.ls2, res=x)
+            return
         ops.layernorm(x, layer.norm2.weight, layer.norm2.bias, h, vc.layer_norm_eps)
         ops.gemm(h, layer.mlp.fc1.weight, f, EPI_BIAS_GELU, bias=layer.mlp.fc1.bias)
         ops.gemm(f, layer.mlp.fc2.weight, x, EPI_SCALE_RES, bias=layer.mlp.fc2.bias, scale=layer.ls2, res=x)
@@ -651,7 +691,7 @@ class InternVLChatRewardModeling(nn.Module):
                 qkv = torch.empty(tiles * T, 3 * dim, dtype=BF16, device=dev)
                 f = torch.empty(tiles * T, vc.intermediate_size, dtype=BF16, device=dev)
                 cu = torch.arange(0, (tiles + 1) * T, T, dtype=torch.int32, device=dev)
-                self._vit_layer(self.model.vision_model.encoder.layers[li], xs, h, qkv, f, cu, T)
+                self._vit_layer(self.model.vision_model.encoder.layers[li], xs, h, qkv, f, cu, T, li)
             finally:
                 ops.set_gemm_workspace(None)
         return xs.view(tiles, T, dim)
@@ -718,17 +758,30 @@ class InternVLChatRewardModeling(nn.Module):
                 ops.embed_gather(sel_rows, hn, att_s, -1)     # row gathers (table = activation rows)
                 ops.embed_gather(sel_rows, x, x_s, -1)
                 ops.gemm(att_s, layer.attention.wo.weight, x_s, EPI_SCALE_RES, res=x_s)
-                ops.rmsnorm(x_s, layer.ffn_norm.weight, hn_s, lc.rms_norm_eps)
-                ops.gemm(hn_s, d["w13"][li], act_s, EPI_SILU_MUL)
-                ops.gemm(act_s, layer.feed_forward.w2.weight, x_s, EPI_SCALE_RES, res=x_s)
+                self._llm_ffn(d, li, layer, x_s, hn_s, act_s, "sel")
                 return x_s
             ops.gemm(hn, layer.attention.wo.weight, x, EPI_SCALE_RES, res=x)
-            ops.rmsnorm(x, layer.ffn_norm.weight, hn, lc.rms_norm_eps)
-            ops.gemm(hn, d["w13"][li], act, EPI_SILU_MUL)
-            ops.gemm(act, layer.feed_forward.w2.weight, x, EPI_SCALE_RES, res=x)
+            self._llm_ffn(d, li, layer, x, hn, act, "all")
             if self.debug_probes is not None:
                 self.debug_probes[f"llm_layer{li}"] = x.clone()
         return x
+
+    def _llm_ffn(self, d, li: int, layer, x, hn, act, tag: str):
+        """x += w2(silu(w1 h) * w3 h), h = ffn_norm(x)  (modeling_internlm2.py:261-264,669-679) in place on the rows ``x``;
+        ``hn`` / ``act`` bf16 scratch of [rows, hidden] / [rows, intermediate].  mxfp8: the norm and the SiLU-mul epilogue write
+        e4m3 + block scales, both GEMMs run on MXFP8 operands."""
+        lc = self.config.llm_config
+        if self.ffn_format == "mxfp8":
+            rows, dev = x.shape[0], x.device
+            h8 = self._buf8(f"llm_h8_{tag}", rows, x.shape[1], dev)
+            a8 = self._buf8(f"llm_a8_{tag}", rows, lc.intermediate_size, dev)
+            ops.rmsnorm_mxfp8(x, layer.ffn_norm.weight, h8, lc.rms_norm_eps)
+            ops.gemm(h8, d["w13_8"][li], a8, EPI_SILU_MUL)
+            ops.gemm(a8, d["w2_8"][li], x, EPI_SCALE_RES, res=x)
+            return
+        ops.rmsnorm(x, layer.ffn_norm.weight, hn, lc.rms_norm_eps)
+        ops.gemm(hn, d["w13"][li], act, EPI_SILU_MUL)
+        ops.gemm(act, layer.feed_forward.w2.weight, x, EPI_SCALE_RES, res=x)
 
     # -- forward ---------------------------------------------------------------------------------
     def _forward_group(self, d, tag: str, pixel_values, host_ids, outs, lo: int, probes_ok: bool):

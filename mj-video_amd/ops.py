@@ -13,8 +13,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_ROPE_QKV, EPI_SCALE_RES, EPI_SILU_MUL, AttnDesc, GemmDesc,
-                   HeadsDesc, check, load_library)
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_ROPE_QKV, EPI_SCALE_RES, EPI_SILU_MUL, FMT_MXFP8, AttnDesc,
+                   GemmDesc, HeadsDesc, check, load_library)
 
 BF16 = torch.bfloat16
 
@@ -38,6 +38,54 @@ def _chk_bf16(*ts):
 def _row_stride(t: torch.Tensor) -> int:
     assert t.dim() == 2 and t.stride(1) == 1, "rows must be contiguous"
     return t.stride(0)
+
+
+class MX8:
+    """An MXFP8 matrix on the GPU (include/mjv.h "MXFP8 operand format"): ``data`` uint8 [rows, cols] OCP e4m3 elements, ``scales``
+    uint8 e8m0 block scales in the MFMA's lane layout (``mxfp8_scale_bytes(rows, cols)`` bytes).  Operand / output of the fp8
+    FFN GEMMs; produced by ``quantize_mxfp8``, the ``*_mxfp8`` norms and ``gemm(..., out=MX8)``."""
+    __slots__ = ("data", "scales")
+
+    def __init__(self, data: torch.Tensor, scales: torch.Tensor):
+        assert data.dtype == torch.uint8 and scales.dtype == torch.uint8 and data.is_cuda and scales.is_cuda
+        assert data.dim() == 2 and data.stride(1) == 1 and data.shape[1] % 128 == 0, "MXFP8: [rows, cols % 128 == 0] row-contiguous"
+        assert scales.is_contiguous() and scales.numel() >= mxfp8_scale_bytes(data.shape[0], data.shape[1])
+        self.data, self.scales = data, scales
+
+    @staticmethod
+    def empty(rows: int, cols: int, device) -> "MX8":
+        return MX8(torch.empty(rows, cols, dtype=torch.uint8, device=device),
+                   torch.empty(mxfp8_scale_bytes(rows, cols), dtype=torch.uint8, device=device))
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def rows(self, n: int) -> "MX8":
+        """the first ``n`` rows (same scale buffer: the records are indexed by absolute row; the GROUP count of the scale
+        layout follows the row count, so only a view with the same ceil(rows / 64) addresses the same records)"""
+        assert (n + 63) // 64 == (self.data.shape[0] + 63) // 64, "a row view must keep the number of 64-row scale groups"
+        return MX8(self.data[:n], self.scales)
+
+
+def mxfp8_scale_bytes(rows: int, cols: int) -> int:
+    return (cols // 128) * ((rows + 63) // 64) * 256
+
+
+def quantize_mxfp8(x: torch.Tensor, out: Optional[MX8] = None) -> MX8:
+    """bf16 [rows, cols] -> MXFP8 (weights once at load; tests)."""
+    _chk_bf16(x)
+    rows, cols = x.shape
+    out = MX8.empty(rows, cols, x.device) if out is None else out
+    assert tuple(out.shape) == (rows, cols)
+    with torch.cuda.device(x.device):
+        check(load_library().mjv_quantize_mxfp8(x.data_ptr(), _row_stride(x), out.data.data_ptr(), _row_stride(out.data),
+                                                out.scales.data_ptr(), rows, cols, _stream(x)), "mjv_quantize_mxfp8")
+    return out
 
 
 class _CallDefaults(threading.local):
@@ -64,6 +112,36 @@ def set_gemm_workspace(ws: Optional[torch.Tensor]) -> None:
     _tls.gemm_ws = ws
 
 
+def _gemm_mxfp8(a: MX8, w: MX8, out, epilogue: int, bias, scale, res, M: Optional[int]):
+    """MXFP8 operands (include/mjv.h, ABI 5): ``out`` a bf16 tensor or an ``MX8`` (the epilogue's result block-quantised)."""
+    assert isinstance(w, MX8), "MXFP8 activations need MXFP8 weights"
+    _chk_bf16(bias, scale, res)
+    d = GemmDesc()
+    d.A, d.lda = a.data.data_ptr(), _row_stride(a.data)
+    d.W, d.ldw = w.data.data_ptr(), _row_stride(w.data)
+    d.M = a.shape[0] if M is None else M
+    assert d.M == a.shape[0], "an MXFP8 operand's scale records are laid out for its own row count"
+    d.N, d.K = w.shape[0], w.shape[1]
+    assert a.shape[1] == d.K, (a.shape, w.shape)
+    d.a_format = d.w_format = FMT_MXFP8
+    d.a_scales, d.w_scales = a.scales.data_ptr(), w.scales.data_ptr()
+    nout = d.N // 2 if epilogue == EPI_SILU_MUL else d.N
+    if isinstance(out, MX8):
+        assert tuple(out.shape) == (d.M, nout), (tuple(out.shape), d.M, nout)
+        d.C, d.ldc, d.c_format, d.c_scales = out.data.data_ptr(), _row_stride(out.data), FMT_MXFP8, out.scales.data_ptr()
+        dev = out.data.device
+    else:
+        _chk_bf16(out)
+        d.C, d.ldc = out.data_ptr(), _row_stride(out)
+        dev = out.device
+    d.epilogue = epilogue
+    d.bias, d.scale = _p(bias), _p(scale)
+    d.res, d.ldr = _p(res), (_row_stride(res) if res is not None else 0)
+    with torch.cuda.device(dev):
+        check(load_library().mjv_gemm_bf16(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "mjv_gemm_bf16(mxfp8)")
+    return out
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_BIAS,
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, res_mod: int = 0, res_off: int = 0, out_group: int = 0,
@@ -72,7 +150,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     """out = epilogue(a[M,K] @ w[N,K]^T); 2-D row-contiguous bf16 views (row strides are honoured).
     ``rope`` (EPI_ROPE_QKV only) = (cos, sin, positions, q_out, k_out, group): see include/mjv.h.
     ``workspace``: split-K scratch of THIS call (default: the calling thread's ``set_gemm_workspace`` buffer);
-    ``tile``: 0 automatic, 64 / 128 / 256 force one tile kernel (default: the calling thread's ``gemm_set_tile`` value)."""
+    ``tile``: 0 automatic, 64 / 128 / 256 force one tile kernel (default: the calling thread's ``gemm_set_tile`` value).
+    ``a`` and ``w`` may be ``MX8`` (MXFP8 operands, ABI 5), ``out`` then a bf16 tensor or an ``MX8``."""
+    if isinstance(a, MX8):
+        assert res_mod == 0 and out_group == 0 and out_rows is None and rope is None, "MXFP8 GEMMs write plain rows"
+        return _gemm_mxfp8(a, w, out, epilogue, bias, scale, res, M)
     _chk_bf16(a, w, out, bias, scale, res)
     lib = load_library()
     d = GemmDesc()
@@ -187,6 +269,27 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, eps: float,
     with torch.cuda.device(out.device):
         check(lib.mjv_rmsnorm_bf16(x.data_ptr(), _row_stride(x), out.data_ptr(), _row_stride(out), w.data_ptr(),
                                    _p(row_index), out.shape[0], out.shape[1], eps, _stream(out)), "mjv_rmsnorm_bf16")
+    return out
+
+
+def layernorm_mxfp8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: MX8, eps: float) -> MX8:
+    """``layernorm`` with the bf16 result block-quantised on the way out (the input of the fp8 fc1 GEMM)."""
+    _chk_bf16(x, gamma, beta)
+    assert tuple(out.shape) == tuple(x.shape)
+    with torch.cuda.device(x.device):
+        check(load_library().mjv_layernorm_mxfp8(x.data_ptr(), _row_stride(x), out.data.data_ptr(), _row_stride(out.data),
+                                                 out.scales.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.shape[0], x.shape[1],
+                                                 eps, _stream(x)), "mjv_layernorm_mxfp8")
+    return out
+
+
+def rmsnorm_mxfp8(x: torch.Tensor, w: torch.Tensor, out: MX8, eps: float) -> MX8:
+    _chk_bf16(x, w)
+    assert tuple(out.shape) == tuple(x.shape)
+    with torch.cuda.device(x.device):
+        check(load_library().mjv_rmsnorm_mxfp8(x.data_ptr(), _row_stride(x), out.data.data_ptr(), _row_stride(out.data),
+                                               out.scales.data_ptr(), w.data_ptr(), x.shape[0], x.shape[1], eps, _stream(x)),
+              "mjv_rmsnorm_mxfp8")
     return out
 
 

@@ -25,6 +25,10 @@ import torch.nn.functional as F
 
 GATING_PATTERN = [92542, 92543, 525, 11353, 364]  # moe_reward.py:48
 
+# The five FFN Linears (ViT fc1 / fc2, LLM w1 / w3 / w2) go through this name: F.linear itself (the reference's bf16 math,
+# bit for bit) unless oracle/ref_fp8.py swaps in its MXFP8 operand rounding for the fp8 weight path.
+_ffn_linear = F.linear
+
 
 # --------------------------------------------------------------------------- vision tower
 def _pos_embed(pos: torch.Tensor, grid: int, H: int, W: int) -> torch.Tensor:
@@ -72,9 +76,9 @@ def vit_layer(sd, cfg, i: int, x: torch.Tensor) -> torch.Tensor:
     h = F.layer_norm(x, (d,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], v.layer_norm_eps).to(x.dtype)
     x = x + vit_attention(sd, p + "attn.", v.num_attention_heads, h) * sd[p + "ls1"]
     h = F.layer_norm(x, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], v.layer_norm_eps).to(x.dtype)
-    h = F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+    h = _ffn_linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
     h = F.gelu(h)
-    h = F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    h = _ffn_linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
     return x + h * sd[p + "ls2"]
 
 
@@ -203,8 +207,8 @@ def llm_layer(sd, cfg, i: int, x, mask, cos, sin) -> torch.Tensor:
     h = rms_norm(x, sd[p + "attention_norm.weight"], eps)
     x = x + llm_attention(sd, cfg, p + "attention.", h, mask, cos, sin)
     h = rms_norm(x, sd[p + "ffn_norm.weight"], eps)
-    h = F.linear(F.silu(F.linear(h, sd[p + "feed_forward.w1.weight"])) *
-                 F.linear(h, sd[p + "feed_forward.w3.weight"]), sd[p + "feed_forward.w2.weight"])
+    h = _ffn_linear(F.silu(_ffn_linear(h, sd[p + "feed_forward.w1.weight"])) *
+                    _ffn_linear(h, sd[p + "feed_forward.w3.weight"]), sd[p + "feed_forward.w2.weight"])
     return x + h
 
 

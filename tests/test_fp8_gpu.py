@@ -1,0 +1,291 @@
+"""The MXFP8 FFN weight path (BASELINE configs[4]) on the MI355X, through the C ABI, against oracle/ref_fp8.py.
+
+What is bit-exact: the quantiser (elements AND block scales, in the MFMA's lane layout), the norms with an MXFP8 output, the
+GEMM on small-integer operands (every product and partial sum exact), and the MXFP8-output epilogue against {bf16 output,
+then quantise}.  What carries a tolerance: the GEMM on random operands - the DEQUANTISED operands are the exact inputs of both
+sides, only the fp32 summation order differs, so <= 1 bf16 ulp as for the bf16 GEMM - and the end-to-end model, which is held
+to the fp8 ORACLE within the bf16 path's own kind of bound, and reported (not held) against the bf16 reference.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import bf16_ulps, build_hip_model, make_cfg
+from test_kernels_gpu import assert_close_bf16, rnd
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _mx_to_host(mx):
+    return mx.data.cpu().numpy(), mx.scales.cpu().numpy()
+
+
+def _check_quantised(mx, x_bf16, what):
+    """device MXFP8 (elements + scale records) == oracle quantisation of the bf16 values ``x_bf16`` (CPU tensor)"""
+    from oracle import ref_fp8
+    codes, sb = ref_fp8.mx_quantize(x_bf16)
+    got_codes, got_scales = _mx_to_host(mx)
+    # +0 / -0 are the same element value; the hardware conversion keeps the sign of a zero, so does the oracle: compare bits
+    assert np.array_equal(got_codes, codes), f"{what}: {(got_codes != codes).sum()} of {codes.size} e4m3 elements differ"
+    rec = ref_fp8.mx_scale_records(sb)
+    rows = x_bf16.shape[0]
+    # bytes of rows beyond the matrix (last 64-row group) are never written by the kernels: compare the real rows only
+    mask = ref_fp8.mx_scale_records(np.ones_like(sb)) != 0
+    assert rec.size == got_scales.size or got_scales.size >= rec.size
+    assert np.array_equal(got_scales[:rec.size][mask], rec[mask]), f"{what}: block scales differ (rows {rows})"
+
+
+# ------------------------------------------------------------------------------------------- quantiser
+@pytest.mark.parametrize("rows,cols", [(64, 128), (1, 128), (77, 256), (300, 1024), (1025, 4096), (130, 8192)])
+def test_quantize_mxfp8_bit_exact(cuda, rows, cols):
+    from mj_video_amd import ops
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    # magnitudes over 40 binades row by row, a few exact zeros, whole zero blocks, the block-maximum corner 1.75 / 1.76 * 2^e
+    x = torch.randn(rows, cols, generator=g) * torch.logspace(-20, 20, rows, base=2.0)[:, None]
+    x[torch.rand(rows, cols, generator=g) < 0.02] = 0.0
+    x[0, :64] = 0.0
+    if rows > 2:
+        x[1, :32] = torch.tensor([1.75] + [0.01] * 31)          # amax exactly 448 / 256: no bump
+        x[2, :32] = torch.tensor([1.7578125] + [0.3] * 31)      # the next bf16 above 1.75: the scale moves up one binade
+    x = x.to(BF)
+    mx = ops.quantize_mxfp8(x.to(cuda))
+    torch.cuda.synchronize()
+    _check_quantised(mx, x, f"quantize {rows}x{cols}")
+    # and nothing saturates / no NaN element
+    codes = mx.data.cpu().numpy()
+    assert ((codes & 0x7F) != 0x7F).all()
+
+
+def test_quantize_mxfp8_every_bf16_magnitude(cuda):
+    """every finite bf16 value as a block maximum (block = [v, v/2, v/3, ...]): scale choice and element rounding, exhaustively"""
+    from mj_video_amd import ops
+    u = torch.arange(0, 0x7F80, dtype=torch.int32).to(torch.int16).view(BF).float()        # all non-negative finite bf16
+    u = u[: (u.numel() // 64) * 64]
+    div = torch.arange(1, 33, dtype=torch.float32)
+    x = (u[:, None] / div[None, :]).to(BF)                                                # [n, 32]
+    x = x.reshape(-1, 128)                                                                # 4 blocks per row
+    x[::2] = -x[::2]
+    mx = ops.quantize_mxfp8(x.to(cuda))
+    torch.cuda.synchronize()
+    _check_quantised(mx, x, "every bf16 magnitude")
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,dim", [(130, 128), (1025, 1024), (333, 2048), (70, 4096)])
+def test_norms_mxfp8_equal_bf16_norm_then_quantise(cuda, rows, dim):
+    from mj_video_amd import ops
+    x = rnd(rows, dim, std=2.0, seed=3).to(cuda)
+    g, b = rnd(dim, std=0.2, seed=4).to(cuda) + 1.0, rnd(dim, std=0.1, seed=5).to(cuda)
+    g = g.to(BF)
+    ref = torch.empty_like(x)
+    ops.layernorm(x, g, b, ref, 1e-6)
+    out = ops.MX8.empty(rows, dim, cuda)
+    ops.layernorm_mxfp8(x, g, b, out, 1e-6)
+    torch.cuda.synchronize()
+    _check_quantised(out, ref.cpu(), "layernorm_mxfp8")
+    ops.rmsnorm(x, g, ref, 1e-5)
+    ops.rmsnorm_mxfp8(x, g, out, 1e-5)
+    torch.cuda.synchronize()
+    _check_quantised(out, ref.cpu(), "rmsnorm_mxfp8")
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+# Measured (tools/fp8_debug.py, profiles/r04_c_mfma_fp8_accumulation.txt): the sum of the 128 products INSIDE one
+# v_mfma_scale_f32_16x16x128_f8f6f4 is not a sequential fp32 sum - on random operands it is off by up to 2^-17 of sum|a||w|
+# (K = 128; 2^-19 at K = 1024), against 2^-24.7 for torch's fp32 matmul.  An output with heavy cancellation (|sum| << sum|a||w|)
+# is therefore several bf16 ulps of ITSELF away from the exact sum although every product is exact.  The tolerance of the
+# random-operand tests is stated accordingly: one bf16 ulp of the exact result + 2^-15 * sum|a||w| (4 x the measured maximum).
+ACC_TOL = 2.0 ** -15
+
+
+def _abs_products(aq, wq):
+    return (aq.double().abs() @ wq.double().abs().t())
+
+
+def _quant_pair(a, w, cuda):
+    from mj_video_amd import ops
+    from oracle import ref_fp8
+    a8, w8 = ops.quantize_mxfp8(a.to(cuda)), ops.quantize_mxfp8(w.to(cuda))
+    return a8, w8, ref_fp8.mx_fake_quant(a), ref_fp8.mx_fake_quant(w)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 136, 256), (513, 520, 128), (700, 256, 384), (256, 1024, 640), (2200, 768, 2048), (64, 8, 128)])
+def test_gemm_mxfp8_exact_integers(cuda, M, N, K):
+    """small-integer operands quantise exactly (x * 2^5 <= 256 has <= 4 significant bits) and every partial sum is exact in
+    fp32: the result must be bit-exact - catches any operand-map / scale-record / swizzle / pipeline-race mistake; K = 1, 2,
+    3, 5, 16 K-tiles of the pipeline and of the 4-slot scale ring, M and N ragged against the tile; per-row and per-block
+    power-of-two factors exercise the scales (products stay exact)"""
+    from mj_video_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-8, 9, (M, K), generator=g).float()
+    w = torch.randint(-7, 8, (N, K), generator=g).float()
+    # (exponents in [-1, 1]: |sum| < 56 * 4 * 2048 < 2^19 in units of 2^-2 - 21 bits, exact in an fp32 accumulator)
+    a = a * torch.exp2(torch.randint(-1, 2, (M, K // 32), generator=g).float()).repeat_interleave(32, dim=1)
+    w = w * torch.exp2(torch.randint(-1, 2, (N, K // 32), generator=g).float()).repeat_interleave(32, dim=1)
+    a, w = a.to(BF), w.to(BF)
+    a8, w8, aq, wq = _quant_pair(a, w, cuda)
+    assert torch.equal(aq, a.float()) and torch.equal(wq, w.float()), "the integer operands must quantise exactly"
+    out = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(a8, w8, out, ops.EPI_BIAS)
+    ref = (a.double() @ w.double().t()).float().to(BF)
+    assert torch.equal(out.cpu(), ref), f"{(out.cpu() != ref).sum().item()} of {ref.numel()} differ"
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (1025, 3072, 1024), (77, 512, 256), (640, 1024, 4096)])
+def test_gemm_mxfp8_bias_random(cuda, M, N, K):
+    from mj_video_amd import ops
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, std=0.05, seed=2), rnd(N, std=0.1, seed=3)
+    a8, w8, aq, wq = _quant_pair(a, w, cuda)
+    out = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(a8, w8, out, ops.EPI_BIAS, bias=b.to(cuda))
+    exact = aq.double() @ wq.double().t() + b.double()
+    ref = exact.float().to(BF)
+    T = _abs_products(aq, wq)
+    err = (out.double().cpu() - exact).abs()
+    ok = err <= exact.abs() * 2.0 ** -8 + ACC_TOL * T
+    assert ok.all(), f"{int((~ok).sum())} of {ok.numel()} outputs beyond 1 bf16 ulp + 2^-15 sum|a||w| (worst excess / T: {((err - exact.abs() * 2.0 ** -8) / T).max().item():.2e})"
+    assert (bf16_ulps(out.float().cpu(), ref.float()) == 0).float().mean().item() >= 0.97
+    # how far the fp8 product is from the bf16 product of the unquantised operands: reported, loosely bounded (2^-4 operands)
+    full = (a.double() @ w.double().t() + b.double()).float()
+    rel = ((out.float().cpu() - full).norm() / full.norm()).item()
+    assert rel < 0.06, rel
+
+
+def test_gemm_mxfp8_epilogues(cuda):
+    """GELU / ReLU / LayerScale+residual / SiLU-mul epilogues on MXFP8 operands = the bf16 kernels' epilogue code on the fp8
+    accumulators: against the same torch composition as tests/test_kernels_gpu.py, fed the dequantised operands"""
+    from mj_video_amd import ops
+    M, N, K = 515, 512, 256
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, std=0.1, seed=2), rnd(N, std=0.1, seed=3)
+    a8, w8, aq, wq = _quant_pair(a, w, cuda)
+    lin = (aq.double() @ wq.double().t() + b.double()).float().to(BF)
+    atol = ACC_TOL * _abs_products(aq, wq).max().item()     # (see ACC_TOL: near-zero outputs of a cancelling sum)
+    out = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(a8, w8, out, ops.EPI_BIAS_GELU, bias=b.to(cuda))
+    # (as test_kernels_gpu.py::test_gemm_gelu_relu: GELU's negative tail amplifies a 1-ulp flip of the Linear - relative
+    # sensitivity ~ -9 at x = -3 - on outputs below 1e-2: absolute floor 2e-3)
+    # and where x in [2, 2.05) maps to gelu(x) in [1.95, 2) one ulp of x is 2.2 ulps of the result: 3 ulps
+    assert_close_bf16(out, F.gelu(lin), 3, frac_exact=0.96, atol=max(atol, 2e-3), what="mxfp8 gelu")
+    ops.gemm(a8, w8, out, ops.EPI_BIAS_RELU, bias=b.to(cuda))
+    assert_close_bf16(out, F.relu(lin), 2, frac_exact=0.97, atol=atol, what="mxfp8 relu")
+    ls, res = rnd(N, std=0.3, seed=4), rnd(M, N, seed=5)
+    ops.gemm(a8, w8, out, ops.EPI_SCALE_RES, bias=b.to(cuda), scale=ls.to(cuda), res=res.to(cuda))
+    ref = (res.float() + (lin.float() * ls.float()).to(BF).float()).to(BF)
+    # (as the bf16 test: a 1-ulp flip of the rounded GEMM term, |v| up to ~4 -> 2^-6, survives cancellation against the residual)
+    assert_close_bf16(out, ref, 2, frac_exact=0.95, atol=0.02, what="mxfp8 scale_res")
+    # in place on the residual stream, as the model calls it
+    x = res.to(cuda).clone()
+    ops.gemm(a8, w8, x, ops.EPI_SCALE_RES, bias=b.to(cuda), scale=ls.to(cuda), res=x)
+    assert torch.equal(x, out)
+    # SiLU-mul on 16-row interleaved w1 | w3
+    ff = 256
+    w1, w3 = rnd(ff, K, std=0.1, seed=6), rnd(ff, K, std=0.1, seed=7)
+    w13 = torch.stack([w1.view(ff // 16, 16, K), w3.view(ff // 16, 16, K)], dim=1).reshape(2 * ff, K).contiguous()
+    w13_8 = ops.quantize_mxfp8(w13.to(cuda))
+    from oracle import ref_fp8
+    g = (aq.double() @ ref_fp8.mx_fake_quant(w1).double().t()).float().to(BF)
+    u = (aq.double() @ ref_fp8.mx_fake_quant(w3).double().t()).float().to(BF)
+    ref = (F.silu(g.float()).to(BF).float() * u.float()).to(BF)
+    o2 = torch.empty(M, ff, dtype=BF, device=cuda)
+    ops.gemm(a8, w13_8, o2, ops.EPI_SILU_MUL)
+    assert_close_bf16(o2, ref, 3, frac_exact=0.92, atol=max(atol, 2e-3), what="mxfp8 silu_mul")
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "relu", "silu"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (515, 1024, 256), (1100, 512, 1024)])
+def test_gemm_mxfp8_output_equals_bf16_output_then_quantise(cuda, epi, M, N, K):
+    """c_format MXFP8: bit-identical (elements and scale records) to the same GEMM with a bf16 output followed by the
+    quantiser - the fused epilogue changes where the bytes go, not what they are"""
+    from mj_video_amd import ops
+    code = dict(bias=ops.EPI_BIAS, gelu=ops.EPI_BIAS_GELU, relu=ops.EPI_BIAS_RELU, silu=ops.EPI_SILU_MUL)[epi]
+    a, w = rnd(M, K, seed=11), rnd(N, K, std=0.08, seed=12)
+    b = None if epi == "silu" else rnd(N, std=0.1, seed=13).to(cuda)
+    a8, w8 = ops.quantize_mxfp8(a.to(cuda)), ops.quantize_mxfp8(w.to(cuda))
+    nout = N // 2 if epi == "silu" else N
+    ref = torch.empty(M, nout, dtype=BF, device=cuda)
+    ops.gemm(a8, w8, ref, code, bias=b)
+    out = ops.MX8.empty(M, nout, cuda)
+    out.data.fill_(0x55)
+    ops.gemm(a8, w8, out, code, bias=b)
+    torch.cuda.synchronize()
+    _check_quantised(out, ref.cpu(), f"mxfp8 output, {epi}")
+
+
+def test_gemm_mxfp8_repeat_launch_stability(cuda):
+    """race screen of the new pipeline pieces (scale ring, 5-instruction counted waits): 200 back-to-back launches of three
+    shapes on a busy chip, every result bit-equal to the first"""
+    from mj_video_amd import ops
+    for M, N, K in ((1024, 1024, 512), (4096, 2048, 2048), (777, 512, 8192)):
+        a8, w8 = ops.quantize_mxfp8(rnd(M, K, seed=21).to(cuda)), ops.quantize_mxfp8(rnd(N, K, std=0.05, seed=22).to(cuda))
+        first = torch.empty(M, N, dtype=BF, device=cuda)
+        ops.gemm(a8, w8, first, ops.EPI_BIAS)
+        out = torch.empty_like(first)
+        bad = 0
+        for _ in range(200):
+            ops.gemm(a8, w8, out, ops.EPI_BIAS)
+            bad += int(not torch.equal(out, first))
+        assert bad == 0, f"{M}x{N}x{K}: {bad} of 200 launches differ from the first"
+
+
+def test_gemm_mxfp8_argument_errors(cuda):
+    from mj_video_amd import ops, _lib
+    a8, w8 = ops.quantize_mxfp8(rnd(64, 128).to(cuda)), ops.quantize_mxfp8(rnd(64, 128).to(cuda))
+    out = torch.empty(64, 64, dtype=BF, device=cuda)
+    with pytest.raises(_lib.MjvLibraryError, match="residual"):
+        ops.gemm(a8, w8, out, ops.EPI_SCALE_RES)   # no residual given
+    with pytest.raises(AssertionError):
+        ops.gemm(a8, rnd(64, 128).to(cuda), out, ops.EPI_BIAS)                              # mixed operand formats
+
+
+# ------------------------------------------------------------------------------------------- model
+def _tiny_model_and_batch(cuda, seed=21):
+    from mj_video_amd import synth
+    from mj_video_amd.chat_input import num_image_tokens_per_tile
+    cfg = make_cfg("tiny", 56)
+    sd = synth.synth_state_dict(cfg, seed=seed)                      # bf16 tensors, checkpoint layout
+    model = build_hip_model(cfg, sd, cuda)
+    per = num_image_tokens_per_tile(cfg)
+    px = torch.cat([synth.synth_pixel_values(9, 0, 4, 56), synth.synth_pixel_values(9, 1, 3, 56)])
+    ids, mask = synth.pad_batch([synth.synth_input_ids(4 * per, 1), synth.synth_input_ids(3 * per, 2)])
+    return cfg, sd, model, px, ids, mask
+
+
+def test_model_mxfp8_against_fp8_oracle_tiny(cuda):
+    """the whole forward with the mxfp8 FFN path against oracle/ref_fp8.py (right-padded batch of two, tiny dims - every FFN
+    K is 128, 256 or 512): each CustomOutput field as close to the fp8 oracle as the bf16 path is to the bf16 oracle on the same
+    inputs (x 3 + a floor: the kernels around the FFN and the accumulation-order noise are the same; an activation that lands
+    on the other side of an e4m3 rounding boundary moves by 2^-4 of itself, not 2^-9), and the fp8-vs-bf16 distance reported"""
+    from mj_video_amd import synth
+    from oracle import ref_cpu, ref_fp8
+    cfg, sd, model, px, ids, mask = _tiny_model_and_batch(cuda)
+    model.set_ffn_format("mxfp8")
+    out8 = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+    model.set_ffn_format("bf16")
+    out16 = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+    torch.cuda.synchronize()
+    ref8 = ref_fp8.reward_forward_fp8(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID)
+    ref16 = ref_cpu.reward_forward(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID)
+    worst = {}
+    for k in ("score", "aspect_scores", "rewards", "aspect_gating_output", "aspect_weights", "criteria_gating_output", "hidden_state"):
+        d8 = (getattr(out8, k).float().cpu() - ref8[k].float()).abs().max().item()
+        d16 = (getattr(out16, k).float().cpu() - ref16[k].float()).abs().max().item()
+        gap = (ref8[k].float() - ref16[k].float()).abs().max().item()
+        worst[k] = (round(d8, 5), round(d16, 5), round(gap, 5))
+        assert d8 <= 3.0 * d16 + 0.02 * max(1.0, ref8[k].float().abs().max().item()), (k, worst[k])
+    print("tiny: |hip8 - oracle8|, |hip16 - oracle16|, |oracle8 - oracle16| per field:", worst)
+    # switching formats changes the result (the path is really taken)
+    assert worst["hidden_state"][2] > 0 and not torch.equal(out8.score, out16.score)
+
+
+def test_model_mxfp8_deterministic_and_reprepares(cuda):
+    cfg, sd, model, px, ids, mask = _tiny_model_and_batch(cuda, seed=22)
+    a = model.set_ffn_format("mxfp8").forward(px.to(cuda), ids.to(cuda), mask.to(cuda)).score.clone()
+    b = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda)).score.clone()
+    assert torch.equal(a, b)
+    c = model.set_ffn_format("bf16").forward(px.to(cuda), ids.to(cuda), mask.to(cuda)).score.clone()
+    d = model.set_ffn_format("mxfp8").forward(px.to(cuda), ids.to(cuda), mask.to(cuda)).score.clone()
+    assert torch.equal(a, d) and not torch.equal(a, c)
+    with pytest.raises(ValueError):
+        model.set_ffn_format("int4")
