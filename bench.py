@@ -39,6 +39,7 @@ from mj_video_amd.chat_input import num_image_tokens_per_tile  # noqa: E402
 from mj_video_amd.modeling import InternVLChatRewardModeling  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled K = 128 MFMA), same table
 HBM_PEAK_GBS = 8000.0
 ALGO_TFLOP_PER_PAIR = 25.8       # 12.9 TFLOP per video at C2 (causal-halved, LM head skipped)
 
@@ -151,11 +152,18 @@ def main():
                     help="skip the single-video latency section (profiling runs: keeps small-batch launches out of the "
                          "per-kernel statistics)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE configs[4]'s weight path on the 2B stand-in: the five FFN Linears of both towers on MXFP8 (e4m3, "
+                         "block-32 e8m0 scales) operands, fp32 accumulate (model.set_ffn_format('mxfp8')).  Its own line, its own "
+                         "dtype and tolerance (DESIGN §7.4) - never the default, never the headline")
     args = ap.parse_args()
     if args.pairs is None:
         args.pairs = 4 if args.gpus == 1 else 8
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # MJV_BENCH_FORCE_LAUNCHER=1: take the N > 1 path (child torch.distributed.run, RCCL init, score_pairs_dp's all-gather,
+    # ranks_seen) at --gpus 1 too - so a 1-GPU box can execute, and a -m gpu test can cover, the code an 8-GPU run goes through
+    force_dist = bool(os.environ.get("MJV_BENCH_FORCE_LAUNCHER"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
         # No launcher: start the N ranks as fresh children (one process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE
         # this process has made any GPU call - it never does: it waits, passes the children's output (rank 0's JSON line)
         # through and exits with their code.  Never re-exec a process that has initialised the GPU.
@@ -177,7 +185,8 @@ def main():
         raise SystemExit("bench.py needs MI355X GPUs: the scoring path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or (force_dist and "WORLD_SIZE" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -188,6 +197,8 @@ def main():
     model.config.pad_token_id = synth.PAD_ID
     model.model.img_context_token_id = synth.IMG_CONTEXT_ID
     model.eval()
+    if args.fp8:
+        model.set_ffn_format("mxfp8")
     for code in args.gemm_code:   # (bench build of the library only: MJV_LIBRARY=.../libmjv_hip_bench.so)
         ops.gemm_set_tile(code)
 
@@ -217,7 +228,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -253,7 +264,7 @@ def main():
         raise SystemExit("non-finite scores")
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     ranks_seen = 1
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         who = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(who, torch.tensor([rank], dtype=torch.int64, device=dev))   # RCCL all-gather
@@ -267,21 +278,33 @@ def main():
             "metric": METRIC,
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
+            "vs_baseline": None,
+            "dtype": ("fp8-e4m3 (MXFP8, block-32 e8m0 scales) operands + fp32 accumulate in the FFN GEMMs, bf16 elsewhere"
+                      if args.fp8 else "bf16"),
+            "data": "synthetic", "ranks_seen": ranks_seen,
+            "process_group": ("nccl" if use_dist else None),
             "config": {"workload": (f"MJ-VIDEO-2B, batch={args.pairs * world} pairs"
                                     + (f" sharded DP over {world} MI355X ({args.pairs} pairs per GPU), RCCL all-gather rewards"
                                        if world > 1 else " on 1 MI355X")
                                     + f", {F} frames @{S}^2 max_num=1, N={seq_len} tokens/video, random-init weights, inputs "
                                       "resident in HBM"),
-                       "baseline_config": ("configs[1]" if (world, args.pairs, S, F) == (1, 4, 448, 8) else
+                       "baseline_config": ("configs[4] weight path on the 2B stand-in (no 4B reference exists): FFN GEMMs only; NOT the headline"
+                                           if args.fp8 else "configs[1]" if (world, args.pairs, S, F) == (1, 4, 448, 8) else
                                            "configs[2] shard size (8 pairs per GPU; 64 pairs at 8 GPUs)"
                                            if (args.pairs, S, F) == (8, 448, 8) and world > 1 else "other"),
                        "pairs_per_gpu_per_step": args.pairs, "global_pairs_per_step": args.pairs * world,
+                       "scaling_note": ("weak scaling at a fixed per-GPU batch; the default per-GPU batch is 4 pairs at --gpus 1 "
+                                        "(configs[1]) and 8 at --gpus N > 1 (configs[2]): an efficiency against N = 1 needs "
+                                        "`--gpus 1 --pairs 8` as its baseline"),
                        "ids": "fresh id / mask tensors every step (one device->host copy of the ids per forward)",
                        "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
             "frac_of_mfma_roofline": round(value * ALGO_TFLOP_PER_PAIR / (MFMA_BF16_PEAK_TFLOPS * world), 4)
-            if (S, F) == (448, 8) else None,
+            if (S, F) == (448, 8) and not args.fp8 else None,
         }
+        from mj_video_amd import _lib
+        lib_path = os.environ.get("MJV_LIBRARY") or _lib.LIB_PATH
+        line["library"] = {"path": os.path.relpath(lib_path, ROOT), "bench_build": hasattr(_lib.load_library(), "mjv_bench_gemm_set")
+                           and getattr(_lib.load_library().mjv_bench_gemm_set, "argtypes", None) is not None}
         if prof:
             res = ops.prof_results()
 
@@ -300,8 +323,9 @@ def main():
                 tot = sum(r["ms"] for r in share_from.values())
                 name, r = max(res.items(), key=lambda kv: kv[1]["ms"])
                 tfl = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
-                return {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4),
+                peak = MFMA_FP8_PEAK_TFLOPS if name.startswith("gemm256f8") else MFMA_BF16_PEAK_TFLOPS
+                return {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(tfl / peak, 4),
                         # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes of this same workload
                         # (profiles/rNN_pmc_traffic.json; a PMC run cannot be nested inside this process)
                         "traffic": traffic.get(name), **({"traffic_note": traffic_note} if traffic_note else {}),
@@ -318,7 +342,7 @@ def main():
             line["roofline"] = roofline(res, args.steps, share_from=res_all)
             line["roofline"]["note"] = "events around this kernel's launches on the launch stream inside the timed region"
             line["kernels"] = table(res_all, 1)
-        if world == 1 and not args.no_latency:
+        if world == 1 and not args.no_latency and not args.fp8:
             # the reference's real call pattern: ONE video per forward (eval_genai_mjvideo.py:140-141), fresh ids each time
             px1, ids1, mask1 = px[:F].contiguous(), ids[:1].contiguous(), mask[:1].contiguous()
             for _ in range(2):
@@ -337,7 +361,7 @@ def main():
             line["latency"] = {"one_video_per_forward_ms": round(lat_ms, 3), "host_enqueue_ms": round(host_ms, 3),
                                "pairs_per_s_at_batch_1_video": round(0.5e3 / lat_ms, 3),
                                "note": "back-to-back single-video forwards, not part of `value`"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.fp8:
             # oneDNN bf16 GEMMs stop scaling (and oversubscribe NUMA domains) far below a 256-thread host: cap at 32
             cpu_model, phys, logical = host_cpu_info()
             threads = min(phys, 32)
@@ -356,7 +380,7 @@ def main():
             except Exception as e:  # the baseline is informational; never lose the GPU number over it
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

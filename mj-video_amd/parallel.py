@@ -41,29 +41,43 @@ def score_pairs_dp(score_fn: Callable[[Sequence], torch.Tensor], pairs: Sequence
         return score_fn(pairs).float()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(len(pairs), world, rank)
-    local = score_fn(pairs[lo:hi]).float() if hi > lo else None
     per = -(-len(pairs) // world)  # all_gather_into_tensor needs equal blocks: pad to the largest shard
-    bad_width = None
-    if local is None:
-        if device is None:
-            raise ValueError("a rank with an empty shard needs `device` to build its (padding) block")
-    else:
+    # whatever goes wrong in THIS rank's score_fn - an exception, a block of the wrong shape - is reported AFTER the collective,
+    # on every rank: raising before it would leave the other ranks (empty shards included) blocked in the all-gather
+    local, bad_width, error = None, None, None
+    if hi > lo:
+        try:
+            local = score_fn(pairs[lo:hi]).float()
+        except Exception as e:   # noqa: BLE001 - re-raised below, after the collective
+            error = e
+    if local is not None:
         device = local.device
         if local.dim() != 3 or local.shape[1] != 2 or local.shape[-1] != width:
-            bad_width = tuple(local.shape)   # reported AFTER the collective, on every rank: raising here would leave the
-            local = None                     # other ranks (empty shards included) blocked in the all-gather
-    # one trailing status row per block: [0, 0] = 0 ok / 1 this rank's score_fn returned a block of the wrong shape
+            bad_width = tuple(local.shape)
+            local = None
+    if device is None:
+        if dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+            device = torch.device("cuda", torch.cuda.current_device())
+        elif error is not None:
+            device = torch.device("cpu")
+        else:
+            raise ValueError("a rank with an empty shard needs `device` to build its (padding) block")
+    # one trailing status row per block: [0, 0] = 0 ok / 1 wrong block shape / 2 score_fn raised
     block = torch.zeros(per + 1, 2, width, dtype=torch.float32, device=device)
     if local is not None:
         block[:hi - lo] = local
-    if bad_width is not None:
-        block[per, 0, 0] = 1.0
+    if bad_width is not None or error is not None:
+        block[per, 0, 0] = 2.0 if error is not None else 1.0
     out = torch.empty(world * (per + 1), 2, width, dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(out, block, group=group)
     out = out.view(world, per + 1, 2, width)
-    failed = [r for r in range(world) if float(out[r, per, 0, 0]) != 0.0]
+    status = out[:, per, 0, 0].tolist()   # ONE device->host read per step for all ranks' status rows
+    if error is not None:
+        raise error
+    failed = [r for r, c in enumerate(status) if c != 0.0]
     if failed:
-        raise ValueError(f"score_fn returned a block of the wrong shape on rank(s) {failed}"
+        raise ValueError(f"score_fn failed on rank(s) {failed} (status {[status[r] for r in failed]}: 1 = block of the wrong shape, "
+                         "2 = exception, raised there)"
                          + (f" (here: {bad_width}, expected [pairs, 2, {width}]; pass width=...)" if bad_width is not None else ""))
     rows = []
     for r in range(world):

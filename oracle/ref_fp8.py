@@ -92,6 +92,21 @@ def mx_fake_quant(x: torch.Tensor) -> torch.Tensor:
     return mx_dequantize(q, sb).reshape(shp)
 
 
+def mx_fake_quant_fast(x: torch.Tensor) -> torch.Tensor:
+    """``mx_fake_quant`` in multi-threaded torch ops, for the 2B-dims checks (1.4 G weight elements): the same block scale
+    from the same bit arithmetic, the element rounding by torch's float8_e4m3fn cast - equal to the table encoder above on
+    every bf16 value inside the format's range and on random scaled data (tests/test_oracle_golden.py pins the two to each
+    other); exact power-of-two scaling both ways."""
+    shp = x.shape
+    xb = x.detach().to(torch.bfloat16).reshape(-1, shp[-1] // BLOCK, BLOCK)
+    u = xb.view(torch.int16).to(torch.int32) & 0x7FFF
+    b = (((u.amax(dim=2) + 0x1F) >> 7) - 8).clamp_min(1)                      # [rows, blocks]
+    xf = xb.float()
+    scaled = torch.ldexp(xf, (127 - b)[:, :, None].expand_as(xf))
+    q = scaled.to(torch.float8_e4m3fn).float()
+    return torch.ldexp(q, (b - 127)[:, :, None].expand_as(q)).reshape(shp)
+
+
 def mx_scale_records(sb: np.ndarray) -> np.ndarray:
     """scale bytes [rows, K / 32] -> the byte image of include/mjv.h's scale layout (K % 128 == 0): per K-tile of 128 and
     64-row group one 256-byte record, byte (row % 16) * 16 + kb * 4 + (row / 16) % 4.  Bytes of rows beyond ``rows`` are 0."""
@@ -116,18 +131,15 @@ def mx_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None
 
 
 @contextlib.contextmanager
-def fp8_ffn():
-    """inside: oracle/ref_cpu.py's five FFN Linears (fc1, fc2, w1, w3, w2) use ``mx_linear`` (weights are re-quantised per call:
-    cache-free and slow, fine for a checker)"""
+def fp8_ffn(fast: bool = True):
+    """inside: oracle/ref_cpu.py's five FFN Linears (fc1, fc2, w1, w3, w2) round both operands to MXFP8 (``mx_linear``).
+    ``fast``: the torch-op form of the rounding (pinned to the table form by the CPU tests); a weight's rounded copy is NOT
+    kept between calls (a 2B-dims forward would hold 5.6 GB of fp32 copies): every Linear re-rounds its weight."""
     prev = ref_cpu._ffn_linear
-    cache = {}
+    fq = mx_fake_quant_fast if fast else mx_fake_quant
 
     def lin(x, w, b=None):
-        key = (w.data_ptr(), tuple(w.shape))
-        wq = cache.get(key)
-        if wq is None:
-            wq = cache[key] = mx_fake_quant(w)
-        y = F.linear(mx_fake_quant(x), wq)
+        y = F.linear(fq(x), fq(w))
         if b is not None:
             y = y + b.float()
         return y.to(x.dtype)
@@ -139,7 +151,7 @@ def fp8_ffn():
         ref_cpu._ffn_linear = prev
 
 
-def reward_forward_fp8(*args, **kwargs):
+def reward_forward_fp8(*args, fast: bool = True, **kwargs):
     """oracle/ref_cpu.reward_forward with the fp8 FFN path"""
-    with fp8_ffn():
+    with fp8_ffn(fast):
         return ref_cpu.reward_forward(*args, **kwargs)

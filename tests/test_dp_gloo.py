@@ -138,3 +138,44 @@ def test_wrong_width_raises_on_every_rank_after_the_collective():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results[0] == ["ValueError", "ok"] and results[1] == ["ValueError", "ok"]
+
+
+def _raising_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def score_fn(local):             # rank 1's model throws (a bad input, an out-of-memory ...); rank 0 is fine
+        if rank == 1:
+            raise RuntimeError("boom on rank 1")
+        return fake_scores(local)
+
+    try:
+        parallel.score_pairs_dp(score_fn, list(range(4)), device=torch.device("cpu"))
+        outcome = "ok"
+    except RuntimeError as e:
+        outcome = f"RuntimeError: {e}"
+    except ValueError as e:
+        outcome = "ValueError" + (" names rank 1" if "[1]" in str(e) else "")
+    q.put((rank, outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exception_in_score_fn_reaches_every_rank_after_the_collective():
+    """an exception inside one rank's score_fn must not leave the other ranks blocked in the all-gather: the failing rank
+    still joins the collective (status row = 2) and re-raises its own exception afterwards, the others raise a ValueError that
+    names it"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_raising_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] == "RuntimeError: boom on rank 1" and results[0] == "ValueError names rank 1", results

@@ -13,13 +13,14 @@ fp32 sum moves a score); TOL_FACTOR = 3 because the difference of two noise samp
 maximum over a few fixture cases under-estimates the maximum over all the elements compared.  The statistical statements
 (rms deviation, preference agreement on decisive pairs, rank correlation) are made on the rank sets.
 """
+import json
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from util import FIELDS, build_hip_model, case_inputs, load_golden, make_cfg
+from util import FIELDS, ROOT, build_hip_model, case_inputs, load_golden, make_cfg
 
 pytestmark = pytest.mark.gpu
 TOL_FACTOR = 3.0
@@ -243,12 +244,13 @@ def _head_checksum(sd):
     return hashlib.sha1(b"".join(sd[k].contiguous().view(torch.int16).numpy().tobytes() for k in sorted(sd))).hexdigest()
 
 
-def _rank_run(cuda, name, pairs_per_forward):
+def _rank_run(cuda, name, pairs_per_forward, ffn_format="bf16"):
     """Scores every pair of rank set ``name`` ONCE per session (the backbone pass is the expensive part) and returns
     dict(meta, got [P,2,34] under the default synthetic heads, eng [P,2,34] under the engineered heads of
     rankeng_* - computed by ``heads_forward`` on the hidden rows of the very same forwards - or None)."""
-    if name in _RANK_CACHE:
-        return _RANK_CACHE[name]
+    key = name if ffn_format == "bf16" else f"{name}:{ffn_format}"
+    if key in _RANK_CACHE:
+        return _RANK_CACHE[key]
     from mj_video_amd import synth
     from mj_video_amd.chat_input import num_image_tokens_per_tile
     try:
@@ -261,6 +263,7 @@ def _rank_run(cuda, name, pairs_per_forward):
     sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
         cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
     model = build_hip_model(cfg, sd, cuda)
+    model.set_ffn_format(ffn_format)
     nt = meta["n_tiles"]
     H = cfg.llm_config.hidden_size
     got = np.zeros((P, 2, 34), dtype=np.float32)
@@ -300,8 +303,8 @@ def _rank_run(cuda, name, pairs_per_forward):
             eng.reshape(-1, 34)[r0:r0 + blk.shape[0]] = blk
     del model
     torch.cuda.empty_cache()
-    _RANK_CACHE[name] = dict(meta=meta, got=got, eng=eng)
-    return _RANK_CACHE[name]
+    _RANK_CACHE[key] = dict(meta=meta, got=got, eng=eng)
+    return _RANK_CACHE[key]
 
 
 def test_rank_agreement_c1(cuda):
@@ -1078,3 +1081,22 @@ def test_c4_full_112_tiles_end_to_end(cuda):
         rel = ((got - ref).norm() / ref.norm()).item()
         print(f"C4 layer-0 attention, head {head}: relative L2 vs chunked fp32 {rel:.2e}")
         assert rel < 6e-3 and (got - ref).abs().max().item() < 0.03
+
+
+def test_bench_launcher_path_runs_on_one_gpu(cuda):
+    """The N > 1 path of bench.py - child `python -m torch.distributed.run`, RCCL process group, score_pairs_dp's all-gather,
+    ranks_seen - executed at world size 1 (MJV_BENCH_FORCE_LAUNCHER=1): the code the driver's 8-GPU run goes through must have
+    run somewhere before it.  The bench is started as a CHILD process (never exec'd from this one)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MJV_BENCH_FORCE_LAUNCHER="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MJV_LIBRARY", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "2",
+                        "--no-cpu-baseline", "--no-latency"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["process_group"] == "nccl" and line["ranks_seen"] == 1 and line["n_gpus"] == 1
+    assert line["value"] > 0 and line["config"]["global_pairs_per_step"] == 2
+    assert line["library"] == {"path": os.path.join("mj-video_amd", "libmjv_hip.so"), "bench_build": False}

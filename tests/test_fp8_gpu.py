@@ -289,3 +289,134 @@ def test_model_mxfp8_deterministic_and_reprepares(cuda):
     assert torch.equal(a, d) and not torch.equal(a, c)
     with pytest.raises(ValueError):
         model.set_ffn_format("int4")
+
+
+@pytest.mark.parametrize("tower,layer", [("vit", 0), ("vit", 23), ("llm", 0), ("llm", 23)])
+def test_single_layer_mxfp8_at_production_shape(cuda, tower, layer):
+    """ONE layer at MJ-VIDEO-2B dims and the headline sequence lengths (2 x 1025 x 1024 vision rows, 1 x 2186 x 2048 language
+    rows, seed-defined inputs and weights as tests/golden/make_layer_fixtures.py builds them): the HIP layer in mxfp8 mode
+    against the fp8 ORACLE's layer (oracle/ref_cpu.py's layer function under ref_fp8.fp8_ffn), no compounding over 24 layers.
+    Yardsticks measured in the same test: the bf16 HIP layer against the bf16 oracle layer, and the fp8-vs-bf16 gap of the
+    oracle.  Bound: the fp8 HIP layer is within 3 x the bf16 distance + 0.3 % of ITS oracle - two fp8 implementations that sum in
+    different orders disagree on the ~1e-3 of the FFN inputs whose bf16 value sits on an e4m3 rounding boundary, and such an
+    element moves by 2^-3 of itself, not 2^-8 - and at least 3 x closer to it than the bf16 oracle is (the fp8-vs-bf16 gap)."""
+    from util import layer_input_rows, layer_tensors, load_golden
+    from mj_video_amd.modeling import InternVLChatRewardModeling
+    from oracle import ref_cpu, ref_fp8
+    npz, meta = load_golden("layers")
+    m = meta["layers"]
+    case = next(c for c in m["cases"] if c["name"] == f"{tower}_layer{layer}")
+    cfg = make_cfg("2b", m["image_size"])
+    prefix = (f"model.vision_model.encoder.layers.{layer}." if tower == "vit" else f"model.language_model.model.layers.{layer}.")
+    w = layer_tensors(cfg, prefix, m["weight_seed"])
+    cfg.vision_config.num_hidden_layers = 1
+    cfg.llm_config.num_hidden_layers = 1
+    cfg.llm_config.vocab_size = 128
+    model = InternVLChatRewardModeling.from_config(cfg, dtype=BF)
+    for prm in model.parameters():
+        prm.data.zero_()
+    mod = model.model.vision_model.encoder.layers[0] if tower == "vit" else model.model.language_model.model.layers[0]
+    mod.load_state_dict(w, strict=True)
+    model = model.to(BF).to(cuda).eval()
+    x = layer_input_rows(m["input_seed"], case["input_tag"], tuple(case["shape"]))
+    run = model.run_vit_layer if tower == "vit" else model.run_llm_layer
+    y8 = run(0, x).float().cpu() if model.set_ffn_format("mxfp8") else None
+    y16 = run(0, x).float().cpu() if model.set_ffn_format("bf16") else None
+    # the oracle's layer on the same rows / weights (keys as ref_cpu expects them: layer index 0)
+    p0 = "model.vision_model.encoder.layers.0." if tower == "vit" else "model.language_model.model.layers.0."
+    sd = {p0 + k: v for k, v in w.items()}
+
+    def oracle_layer():
+        if tower == "vit":
+            return ref_cpu.vit_layer(sd, cfg, 0, x)
+        B, N, _ = x.shape
+        mask = ref_cpu.causal_padding_mask(torch.ones(B, N, dtype=torch.bool), x.dtype)
+        cos, sin = ref_cpu.rope_tables(cfg, N, x.dtype)
+        return ref_cpu.llm_layer(sd, cfg, 0, x, mask, cos, sin)
+
+    r16 = oracle_layer().float()
+    with ref_fp8.fp8_ffn():
+        r8 = oracle_layer().float()
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm()).item()
+
+    d8, d16, gap = rel(y8, r8), rel(y16, r16), rel(r8, r16)
+    print(f"{tower}_layer{layer} @ production shape: hip8 vs oracle8 {d8:.5f}; hip16 vs oracle16 {d16:.5f}; oracle8 vs oracle16 {gap:.5f}")
+    assert torch.isfinite(y8).all()
+    # measured (profiles/r04_d_fp8_parity.txt): vision 0.47 % against 0.18 % (bf16) and a 2.4 % gap; language 1.1 % / 0.29 % / 4.3 %
+    assert d8 <= 3.0 * d16 + 3e-3, (d8, d16)
+    assert d8 * 3.0 <= gap, (d8, gap)
+
+
+def test_model_mxfp8_against_fp8_oracle_c1_dims(cuda):
+    """MJ-VIDEO-2B dims, one video of 8 tiles @224^2 (BASELINE configs[0]'s shape), mxfp8 FFN path against the fp8 ORACLE
+    run here on the host (about half a minute): final hidden rows and every head output.  The yardstick is measured in the same
+    test: the bf16 HIP path against the bf16 oracle on the same input (the two paths share every kernel but the FFN's)."""
+    from mj_video_amd import synth
+    from mj_video_amd.chat_input import num_image_tokens_per_tile
+    from oracle import ref_cpu, ref_fp8
+    cfg = make_cfg("2b", 224)
+    sd = synth.synth_state_dict(cfg, seed=5, lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=BF).expand(cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
+    model = build_hip_model(cfg, sd, cuda)
+    px = synth.synth_pixel_values(77, 0, 8, 224)
+    ids = synth.synth_input_ids(num_image_tokens_per_tile(cfg) * 8, caption_seed=3)
+    mask = torch.ones_like(ids)
+    out8 = model.set_ffn_format("mxfp8").forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+    out16 = model.set_ffn_format("bf16").forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+    torch.cuda.synchronize()
+    ref8 = ref_fp8.reward_forward_fp8(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID)
+    ref16 = ref_cpu.reward_forward(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID)
+
+    def rel(a, b):
+        a, b = a.float().cpu(), b.float()
+        return ((a - b).norm() / b.norm()).item()
+
+    r8 = {k: rel(getattr(out8, k), ref8[k]) for k in ("hidden_state", "prompt_embedding")}
+    r16 = {k: rel(getattr(out16, k), ref16[k]) for k in ("hidden_state", "prompt_embedding")}
+    gap = {k: rel(ref8[k], ref16[k]) for k in ("hidden_state", "prompt_embedding")}
+    print(f"2B dims @224: relative L2 of the hidden rows: hip8 vs oracle8 {r8}; hip16 vs oracle16 {r16}; oracle8 vs oracle16 {gap}")
+    print(f"score: hip8 {out8.score.item():+.4f} oracle8 {ref8['score'].item():+.4f} | hip16 {out16.score.item():+.4f} oracle16 {ref16['score'].item():+.4f}")
+    # End to end the statement is statistical, as for the bf16 path (DESIGN 2 "how chaotic the path is"): after 48 layers the
+    # per-layer disagreement of two fp8 implementations (single-layer test above: 0.5 % / 1.1 %, about a quarter of the layer's
+    # fp8-vs-bf16 gap) has compounded to about two thirds of the compounded gap (measured 12.3 % against 18.5 %; the bf16 path:
+    # 2.3 %).  Held here: finite, closer to the fp8 oracle than the bf16 oracle is, and within 8 x the bf16 path's own distance;
+    # the single-layer test carries the parity claim, the engineered rank set the end-to-end one (against the REFERENCE).
+    for k in r8:
+        assert r8[k] < gap[k], (k, r8[k], gap[k])
+        assert r8[k] <= 8.0 * r16[k], (k, r8[k], r16[k])
+    for k in ("score", "aspect_scores", "rewards", "aspect_gating_output"):
+        assert torch.isfinite(getattr(out8, k).float()).all(), k
+    d_score = abs(out8.score.item() - ref8["score"].item())
+    assert d_score <= max(abs(ref8["score"].item() - ref16["score"].item()), 0.25), (d_score,)
+
+
+def test_rank_agreement_engineered_c1_mxfp8(cuda):
+    """The fp8 FFN path against the REFERENCE's bf16 scores on the engineered rank set @224^2 (512 pairs, 478 decisive): reported
+    with ITS OWN stated tolerance - this path is not a drop-in for the bf16 numbers (2^-4 operand rounding against 2^-9, through
+    a backbone that amplifies rounding noise): score deviation rms <= 10 x the reference's own bf16-vs-fp32 noise (CPU study,
+    DESIGN 7.4: 7.6 x with per-tensor activation scales; measured here 7.6 x), preference agreement on the decisive pairs
+    >= 0.99 (measured 1.0000), Spearman >= 0.997 (measured 0.9986)."""
+    from scipy.stats import spearmanr
+    from test_e2e_gpu import _rank_run
+    run = _rank_run(cuda, "rankset_c1", 8, ffn_format="mxfp8")
+    if run["eng"] is None:
+        pytest.skip("rankeng_c1 fixture not generated")
+    from util import load_golden
+    enpz, emeta = load_golden("rankeng_c1")
+    ref, keep, got = enpz["ref_bf16"], enpz["keep"], run["eng"][: enpz["ref_bf16"].shape[0]]
+    f32, idx32 = enpz["ref_fp32"], enpz["fp32_pairs"]
+    noise_rms = float(np.sqrt(((ref[idx32][..., 0] - f32[..., 0]) ** 2).mean()))
+    d = (got[..., 0] - ref[..., 0]).ravel()
+    rms = float(np.sqrt((d ** 2).mean()))
+    agree = np.sign(got[:, 0, 0] - got[:, 1, 0]) == np.sign(ref[:, 0, 0] - ref[:, 1, 0])
+    rho = spearmanr(got[..., 0].ravel(), ref[..., 0].ravel()).correlation
+    print(f"mxfp8 FFN vs reference bf16, rankeng_c1: score spread {float(ref[..., 0].std()):.4f}; reference bf16-vs-fp32 noise rms {noise_rms:.5f}; "
+          f"|hip8 - ref| rms {rms:.5f} ({rms / noise_rms:.1f} x) max {np.abs(d).max():.5f}; preference agreement on the {int(keep.sum())} decisive "
+          f"pairs {agree[keep].mean():.5f} ({int((~agree[keep]).sum())} flips), on all {len(agree)} pairs {agree.mean():.5f}; spearman {rho:.6f}")
+    # measured (profiles/r04_d_fp8_parity.txt): rms 0.0600 = 7.6 x the noise, 0 flips on the 478 decisive pairs, 0.9863 on all
+    # 512, rho 0.99863
+    assert rms <= 10.0 * noise_rms
+    assert agree[keep].mean() >= 0.99
+    assert rho >= 0.997

@@ -22,7 +22,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib = _lib.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mjv_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.mjv_abi_version() == _lib.ABI_VERSION == 5
     assert lib.mjv_arch() == b"gfx950"
     assert os.path.dirname(path).endswith("mj-video_amd")  # in-tree, so the driver sees it loaded
     # ABI 4: no process-wide setter in the product header, and the product library neither exports the measurement switches

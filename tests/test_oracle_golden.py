@@ -128,3 +128,60 @@ def test_oracle_reproduces_the_sticky_dynamic_ntk_sequence():
     px, ids, mask, _ = case_inputs(cfg, call["videos"], m["pixel_seed"], m["image_size"])
     fresh = ref_cpu.reward_forward(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID)
     assert np.array_equal(fresh["hidden_state"].float().numpy(), npz["ntk/short_first/hidden_state"])
+
+
+# ------------------------------------------------------------------ MXFP8 operand rounding (oracle/ref_fp8.py)
+def test_fp8_oracle_element_encoder_equals_torch_cast_and_fast_path():
+    """oracle/ref_fp8.py is a DEFINITION (the reference has no fp8 path): its table-driven e4m3 encoder is held to torch's
+    float8_e4m3fn cast on every bf16 value inside the format's range, its block quantiser to the properties the format
+    promises (no saturation, error <= half an e4m3 ulp of the block maximum's binade, power-of-two scales, zero blocks),
+    and the multi-threaded form used at 2B dims to the table form bit for bit."""
+    import numpy as np
+    import torch
+    from oracle import ref_fp8 as R
+    u = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16).float()
+    m = torch.isfinite(u) & (u.abs() <= 448)
+    mine = R.e4m3_encode(u[m].numpy())
+    tc = u[m].to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(mine, tc)
+    assert np.array_equal(R.e4m3_encode(R.e4m3_decode(np.arange(127, dtype=np.uint8))), np.arange(127, dtype=np.uint8))
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(96, 512, generator=g) * torch.logspace(-12, 12, 96, base=2.0)[:, None]).to(torch.bfloat16)
+    x[3, :32] = 0.0
+    x[5, 64:96] = torch.tensor([1.75] + [0.2] * 31)
+    x[6, 64:96] = torch.tensor([1.7578125] + [0.2] * 31)
+    q, sb = R.mx_quantize(x)
+    assert ((q & 0x7F) <= 0x7E).all() and sb.min() >= 1
+    d = R.mx_dequantize(q, sb)
+    blk_amax = x.float().abs().reshape(96, 16, 32).amax(2)
+    err = (d - x.float()).abs().reshape(96, 16, 32).amax(2)
+    assert (err <= blk_amax * (2.0 ** -4) + 1e-30).all()                   # half an ulp of a 3-bit mantissa, at worst 2^-4 of amax
+    assert sb[5, 2] + 1 == sb[6, 2]                                        # 1.75 * 2^e fits, the next bf16 above moves the scale up
+    assert np.array_equal(sb[3, :1], np.array([1], dtype=np.uint8)) and (q[3, :32] == 0).all()
+    assert torch.equal(R.mx_fake_quant(x), R.mx_fake_quant_fast(x))
+    rec = R.mx_scale_records(sb)
+    assert rec.size == (512 // 128) * 2 * 256 and rec[(0 * 2 + 0) * 256 + 5 * 16 + 2 * 4 + 0] == sb[5, 2]
+    assert rec[(1 * 2 + 1) * 256 + (70 % 16) * 16 + 1 * 4 + ((70 >> 4) & 3)] == sb[70, 5]
+
+
+def test_fp8_oracle_hook_leaves_the_bf16_oracle_untouched():
+    """the fp8 mode swaps ONE name in ref_cpu (the five FFN Linears) and restores it: outside the context the pinned bf16
+    oracle computes exactly what it did (tiny fixture, bit for bit), inside it something else"""
+    import torch
+    from mj_video_amd import synth
+    from mj_video_amd.chat_input import num_image_tokens_per_tile
+    from oracle import ref_cpu, ref_fp8
+    from util import make_cfg
+    cfg = make_cfg("tiny", 56)
+    sd = synth.synth_state_dict(cfg, seed=3)
+    px = synth.synth_pixel_values(4, 0, 2, 56)
+    ids = synth.synth_input_ids(2 * num_image_tokens_per_tile(cfg), 1)
+    a = ref_cpu.reward_forward(sd, cfg, px, ids, torch.ones_like(ids), synth.IMG_CONTEXT_ID, synth.PAD_ID)
+    b = ref_fp8.reward_forward_fp8(sd, cfg, px, ids, torch.ones_like(ids), synth.IMG_CONTEXT_ID, synth.PAD_ID)
+    b2 = ref_fp8.reward_forward_fp8(sd, cfg, px, ids, torch.ones_like(ids), synth.IMG_CONTEXT_ID, synth.PAD_ID, fast=False)
+    c = ref_cpu.reward_forward(sd, cfg, px, ids, torch.ones_like(ids), synth.IMG_CONTEXT_ID, synth.PAD_ID)
+    assert ref_cpu._ffn_linear is torch.nn.functional.linear
+    for k in a:
+        assert torch.equal(a[k], c[k]), k
+        assert torch.equal(b[k], b2[k]), k
+    assert not torch.equal(a["hidden_state"], b["hidden_state"])
