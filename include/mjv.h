@@ -146,6 +146,8 @@ int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);
  * Q/K/V/O are addressed as base + row * ld + head * head_stride (elements); K/V head = q_head / kv_group.
  * score rounding: mode 0: s = bf16(acc * scale)   [(q*scale) @ k^T with scale a power of two]
  *                 mode 1: s = bf16(bf16(acc) * scale)   [matmul, then / sqrt(D) in bf16]
+ *                 mode 2: s = acc * scale in fp32, never rounded   [the reference's flash-attention numerics, the path it takes on
+ *                         a GPU: modeling_intern_vit.py:229-244, modeling_internlm2.py:437-561; kernel 0 / 6 / 7 only]
  * ------------------------------------------------------------------------------------------- */
 typedef struct mjv_attn_desc {
   const mjv_bf16 *Q, *K, *V;

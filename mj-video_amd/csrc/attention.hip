@@ -74,7 +74,9 @@ struct Cfg {
 //   RM_MUL   s = bf16(acc * scale)                 [(q * scale) @ k^T, generic scale]
 //   RM_POW2  s = bf16(acc) * scale                 [same thing when scale is a power of two: exact, one op less]
 //   RM_DIV   s = bf16(bf16(acc) * scale)           [q @ k^T, then / sqrt(D) on the bf16 tensor]
-enum { RM_MUL = 0, RM_DIV = 1, RM_POW2 = 2 };
+//   RM_FLASH s = acc * scale in fp32, never rounded [the reference's flash-attention path, which is what it runs on a GPU:
+//            modeling_intern_vit.py:229-244, modeling_internlm2.py:437-561; API score_round_mode 2, attn2_kernel only]
+enum { RM_MUL = 0, RM_DIV = 1, RM_POW2 = 2, RM_FLASH = 3 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -99,6 +101,7 @@ template <int RM>
 MJV_DEV float round_score(float a, float scale) {
   if constexpr (RM == RM_MUL) return rbf(a * scale);
   if constexpr (RM == RM_DIV) return rbf(rbf(a) * scale);
+  if constexpr (RM == RM_FLASH) return a;   // unrounded; the scale is folded into the exp2 argument
   return rbf(a);  // RM_POW2: the scale is folded into the exp2 argument
 }
 
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   if constexpr (NSUB == 2) qi[1] = qw0 + 32 + l31;
 
   constexpr float LOG2E = 1.4426950408889634f;
-  const float c_exp = (RM == RM_POW2) ? p.scale * LOG2E : LOG2E;   // exp2 argument = (rounded score) * c_exp - M
+  const float c_exp = (RM == RM_POW2 || RM == RM_FLASH) ? p.scale * LOG2E : LOG2E;   // exp2 argument = (rounded score) * c_exp - M
 
   // Q fragments (B operand): lane holds Q[query l31][d = 16 ks + 8 hi + j]
   bf16x8 qf[NSUB][F];
@@ -814,7 +817,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   auto do_pair = [&](const f32x16& S, int r, float nmb, float& psum, unsigned& pw) __attribute__((always_inline)) {
     const f32x2 a2 = {S[r], S[r + 1]};
     f32x2 sr;
-    if constexpr (RM == RM_MUL) sr = round_pair(a2 * scale2);
+    if constexpr (RM == RM_FLASH) sr = a2;   // 2 fma + 2 exp + pack + dot2c per pair: no rounding, no separate scaling
+    else if constexpr (RM == RM_MUL) sr = round_pair(a2 * scale2);
     else {
       sr = round_pair(a2);
       if constexpr (RM == RM_DIV) sr = round_pair(sr * scale2);
@@ -1110,7 +1114,8 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
       a.n_qb = nqb2;
       const int total2 = nqb2 * a.n_heads * n_seqs;
       const dim3 grid2(8 * ((total2 + 7) / 8));
-      if (a.round_mode == 1) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_DIV, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
+      if (a.round_mode == 2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_FLASH, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
+      else if (a.round_mode == 1) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_DIV, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
       else if (pow2) hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_POW2, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
       else hipLaunchKernelGGL((v2::attn2_kernel<D, CAUSAL, RM_MUL, NW, NSUB>), grid2, dim3(64 * NW), 0, s, a);
     };
@@ -1164,6 +1169,9 @@ extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
   MJV_REQUIRE(d && d->Q && d->K && d->V && d->O && d->cu_seqlens, "attention: null pointer");
   MJV_REQUIRE(d->head_dim == 64 || d->head_dim == 128, "attention: head_dim %d not in {64,128}", d->head_dim);
   MJV_REQUIRE(d->kernel == 0 || (d->kernel >= 4 && d->kernel <= 7), "attention: kernel %d not in {0, 4, 5, 6, 7}", d->kernel);
+  MJV_REQUIRE(d->score_round_mode >= 0 && d->score_round_mode <= 2, "attention: score_round_mode %d not in {0, 1, 2}", d->score_round_mode);
+  MJV_REQUIRE(d->score_round_mode != 2 || (d->kernel != 4 && d->kernel != 5),
+              "attention: score_round_mode 2 (unrounded fp32 scores) exists in the round-3 kernel only (kernel 0, 6 or 7)");
   MJV_REQUIRE(d->n_seqs > 0 && d->max_seqlen > 0 && d->n_heads > 0 && d->kv_group > 0, "attention: bad sizes");
   MJV_REQUIRE(d->n_heads % d->kv_group == 0, "attention: n_heads %% kv_group != 0");
   MJV_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "attention: ld alignment");

@@ -341,6 +341,15 @@ class InternVLChatRewardModeling(nn.Module):
         # quantised once in _prepare, activations in the producing kernel (norm / GELU / SiLU-mul epilogue).  Not a drop-in for
         # the reference's bf16 numbers: held to oracle/ref_fp8.py and reported with its own tolerance.
         self.ffn_format = "bf16"
+        # The reference ships two attention numerics.  "flash" (default since round 4): fp32 softmax on UNROUNDED scores - its
+        # flash-attention path (modeling_intern_vit.py:229-244, modeling_internlm2.py:437-561), the one it runs on a GPU;
+        # score_round_mode 2 of the C ABI.  "eager": the scores rounded to bf16 before the softmax exactly where its eager path
+        # rounds them (modeling_intern_vit.py:210-227: bf16(q scale) k^T; modeling_internlm2.py:383-411: bf16(bf16(q k^T) / sqrt(d))) -
+        # the path its CPU run (and so the oracle) takes; modes 0 / 1.  The fixtures decided (DESIGN §4 "Attention, round 4",
+        # profiles/r04_e_attention_numerics_gate.txt): against the reference's bf16 AND fp32 runs the two settings are equally
+        # close on every gate (single layers at production shape, full_c1 / full_c2, the engineered rank sets), and the
+        # unrounded form needs 6 instead of 8 (ViT) / 12 (LLM) vector instructions per score pair.
+        self.attention_scores = "flash"
 
     # -- construction helpers -------------------------------------------------------------------
     @classmethod
@@ -658,7 +667,8 @@ class InternVLChatRewardModeling(nn.Module):
         scale = (dim // H) ** -0.5
         ops.layernorm(x, layer.norm1.weight, layer.norm1.bias, h, vc.layer_norm_eps)
         ops.gemm(h, layer.attn.qkv.weight, qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
-        ops.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], h, cu, T, H, 1, 64, False, scale, 0)
+        ops.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], h, cu, T, H, 1, 64, False, scale,
+                      2 if self.attention_scores == "flash" else 0)
         ops.gemm(h, layer.attn.proj.weight, x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
         if self.ffn_format == "mxfp8":
             # norm2 -> fc1 (+GELU) -> fc2 on MXFP8 operands: the norm and the GELU epilogue write e4m3 + block scales
@@ -746,7 +756,8 @@ class InternVLChatRewardModeling(nn.Module):
             # wqkv with the rotary embedding + GQA de-interleave in its epilogue: q / k go (rotated) to their own buffers,
             # v stays in its columns of qkv (modeling_internlm2.py:359-381)
             ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_ROPE_QKV, rope=(cos, sin, positions, q, k, G))
-            ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, 1, v_head_stride=(G + 2) * hd)
+            ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, 2 if self.attention_scores == "flash" else 1,
+                          v_head_stride=(G + 2) * hd)
             if self.debug_probes is not None and li == 0:   # operands / result of the first causal attention (parity tests)
                 self.debug_probes["llm_attn0"] = dict(q=q.clone(), k=k.clone(), v=v_view.clone(), out=hn.clone(), kv_heads=KV)
             if li == last and sel_rows is not None and self.debug_probes is None and only_layer is None:

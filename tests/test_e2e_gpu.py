@@ -103,7 +103,9 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def test_tiny_cases_against_golden(cuda):
+@pytest.mark.parametrize("scores", ["flash", "eager"])
+def test_tiny_cases_against_golden(cuda, scores):
+    """(both of the reference's attention numerics - model.attention_scores - against the same reference-executed fixtures)"""
     from mj_video_amd import synth
     npz, meta = load_golden("tiny")
     names = [c["name"] for c in meta["cases"]]
@@ -113,6 +115,7 @@ def test_tiny_cases_against_golden(cuda):
         cfg = make_cfg("tiny", case["image_size"], case["vit_image_size"])
         sd = synth.synth_state_dict(cfg, seed=case["weight_seed"], dtype=torch.float32)
         model = build_hip_model(cfg, sd, cuda)
+        model.attention_scores = scores
         px, ids, mask, _ = case_inputs(cfg, case["videos"], case["pixel_seed"], case["image_size"])
         model.debug_probes = {}
         out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
@@ -525,8 +528,9 @@ def test_k_sliced_path_is_no_further_from_fp32(cuda):
         assert d_on <= 1.5 * d_ref and d_off <= 1.5 * d_ref, (f, d_on, d_off, d_ref)
 
 
+@pytest.mark.parametrize("scores", ["flash", "eager"])
 @pytest.mark.parametrize("name", ["vit_layer0", "vit_layer23", "llm_layer0", "llm_layer23"])
-def test_single_layer_at_production_shape(cuda, name):
+def test_single_layer_at_production_shape(cuda, name, scores):
     """tests/golden/layers.npz: ONE layer at MJ-VIDEO-2B dimensions and the headline sequence lengths, executed by the
     reference's own InternVisionEncoderLayer.forward (modeling_intern_vit.py:283-295, [2, 1025, 1024]) /
     InternLM2DecoderLayer.forward (modeling_internlm2.py:621-681, [1, 2186, 2048]) on seed-defined bf16 rows with the
@@ -551,7 +555,9 @@ def test_single_layer_at_production_shape(cuda, name):
         prm.data.zero_()
     mod = model.model.vision_model.encoder.layers[0] if case["tower"] == "vit" else model.model.language_model.model.layers[0]
     mod.load_state_dict(w, strict=True)
-    model = model.to(torch.bfloat16).to(cuda).eval()
+    from util import apply_test_overrides
+    model = apply_test_overrides(model.to(torch.bfloat16).to(cuda).eval())
+    model.attention_scores = scores     # both of the reference's attention numerics are held to the same bound
     x = layer_input_rows(m["input_seed"], case["input_tag"], tuple(case["shape"]))
     y = (model.run_vit_layer(0, x) if case["tower"] == "vit" else model.run_llm_layer(0, x)).float().cpu()
     rows = npz[f"{name}/rows"]
@@ -560,7 +566,7 @@ def test_single_layer_at_production_shape(cuda, name):
     f32 = npz[f"{name}/fp32"]
     noise = case["ref_bf16_vs_fp32"]
     d_ref, d_f32 = rel_l2(got, ref), rel_l2(got, f32)
-    print(f"{name}: HIP vs reference bf16 {d_ref:.5f}, HIP vs reference fp32 {d_f32:.5f}; reference bf16 vs fp32 {noise:.5f}")
+    print(f"{name} [{scores} scores]: HIP vs reference bf16 {d_ref:.5f}, HIP vs reference fp32 {d_f32:.5f}; reference bf16 vs fp32 {noise:.5f}")
     assert np.isfinite(got).all()
     assert d_ref <= 2.0 * noise, (name, d_ref, noise)
     assert d_f32 <= 2.0 * noise, (name, d_f32, noise)

@@ -343,7 +343,10 @@ def attn_reference(q, k, v, lens, H, G, D, causal, scale, mode):
             kh = k[s0:s0 + L, (h // G) * D:(h // G + 1) * D].float()
             vh = v[s0:s0 + L, (h // G) * D:(h // G + 1) * D].float()
             sc = qh @ kh.t()
-            sc = (sc.to(BF).float() * scale).to(BF).float() if mode else (sc * scale).to(BF).float()
+            if mode == 2:      # the reference's flash-attention numerics: fp32 scores, never rounded
+                sc = sc * scale
+            else:
+                sc = (sc.to(BF).float() * scale).to(BF).float() if mode else (sc * scale).to(BF).float()
             if causal:
                 sc = sc.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
             p = torch.softmax(sc, -1).to(BF).float()
@@ -382,6 +385,53 @@ def test_attention(cuda, attn_variant, D, H, G, causal, lens):
     assert_close_bf16(out, ref, 2, atol=0.02, what="attention")
 
 
+@pytest.mark.parametrize("kernel", [0, 6])
+@pytest.mark.parametrize("D,H,G,causal,lens", [
+    (64, 2, 1, False, [17, 17, 17]),
+    (64, 16, 1, False, [1025, 1025]),
+    (64, 2, 1, False, [257, 64, 129]),
+    (64, 2, 1, True, [300, 65]),
+    (128, 2, 2, True, [150]),
+    (128, 4, 2, True, [650, 131, 64, 1]),
+    (128, 16, 2, True, [2186]),
+    (128, 4, 2, False, [577]),
+])
+def test_attention_unrounded_scores_mode2(cuda, kernel, D, H, G, causal, lens):
+    """score_round_mode 2 = the reference's flash-attention numerics (modeling_intern_vit.py:229-244, modeling_internlm2.py:
+    437-561: fp32 softmax on unrounded scores), round-3 kernel only: against the fp32 reference WITHOUT the score rounding, same
+    bounds as test_attention; and strictly closer to that reference than the eager-numerics result is (the rounding is really
+    gone); the older kernels refuse the mode."""
+    from mj_video_amd import ops, _lib
+    N = sum(lens)
+    KVH = H // G
+    q, k, v = rnd(N, H * D, seed=1), rnd(N, KVH * D, seed=2), rnd(N, KVH * D, seed=3)
+    scale = D ** -0.5
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    out = torch.empty(N, H * D, dtype=BF, device=cuda)
+    ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), out, cu.to(cuda), max(lens), H, G, D, causal, scale, 2, kernel=kernel)
+    ref = attn_reference(q, k, v, lens, H, G, D, causal, scale, 2)
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    rel = ((o - ref.float()).norm() / ref.float().norm()).item()
+    assert rel < 4e-3, f"relative L2 error {rel:.3e}"
+    assert_close_bf16(out, ref, 2, atol=0.02, what="attention mode 2")
+    eager = torch.empty_like(out)
+    ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), eager, cu.to(cuda), max(lens), H, G, D, causal, scale, 1 if causal else 0, kernel=kernel)
+    rel_eager = ((eager.float().cpu() - ref.float()).norm() / ref.float().norm()).item()
+    if max(lens) >= 64:
+        assert rel <= rel_eager, (rel, rel_eager)
+    with pytest.raises(_lib.MjvLibraryError, match="score_round_mode 2"):
+        ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), out, cu.to(cuda), max(lens), H, G, D, causal, scale, 2, kernel=5)
+
+
+@pytest.mark.parametrize("D,causal,L", [(64, False, 1025), (64, False, 1024), (64, True, 700), (128, True, 2186), (128, False, 577)])
+@pytest.mark.parametrize("ramp", [0.6, 0.12, -0.6])
+def test_attention_rising_scores_mode2(cuda, D, causal, L, ramp):
+    """the offset-raise ramps of the test below through the unrounded-score mode (the raise logic is shared, the rounding of the
+    maximum that sets the new offset is not)"""
+    _rising_scores_case(cuda, D, causal, L, ramp, 2)
+
+
 @pytest.mark.parametrize("D,causal,L", [(64, False, 1025), (64, False, 1024), (64, True, 700), (128, True, 2186), (128, False, 577)])
 @pytest.mark.parametrize("ramp", [0.6, 0.12, -0.6])
 def test_attention_rising_scores_exercise_the_offset_raise(cuda, attn_variant, D, causal, L, ramp):
@@ -391,6 +441,10 @@ def test_attention_rising_scores_exercise_the_offset_raise(cuda, attn_variant, D
     new offset exactly once.  Here the scores RISE along the keys (ramp 0.6 / 0.12 log2 units per key plus noise: a raise every
     ~30 / ~150 keys, each by a few binades, so what was accumulated before stays significant after it), or fall (-0.6: never a
     raise, the first keys dominate).  Against the fp32 reference, same bounds as test_attention."""
+    _rising_scores_case(cuda, D, causal, L, ramp, 1 if causal else 0)
+
+
+def _rising_scores_case(cuda, D, causal, L, ramp, mode):
     from mj_video_amd import ops
     if not causal and L > 600 and ramp > 0.5:
         # (every query sees the top of the ramp: raw scores of +-3 400, where one bf16 ulp of the reference's OWN score rounding is
@@ -400,7 +454,6 @@ def test_attention_rising_scores_exercise_the_offset_raise(cuda, attn_variant, D
     KVH = H // G
     g = torch.Generator().manual_seed(41)
     scale = D ** -0.5
-    mode = 1 if causal else 0
     # q = a fixed direction u (+ noise), k_j = (ramp * j / (scale * log2 e)) * u / |u|^2 (+ noise): q . k_j * scale * log2 e ~ ramp * j
     u = torch.randn(D, generator=g)
     u = u / u.norm()

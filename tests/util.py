@@ -37,6 +37,16 @@ def case_inputs(cfg, case_videos, pixel_seed, image_size):
     return torch.cat(px), ids_b, mask, ids
 
 
+def apply_test_overrides(model):
+    """MJV_TEST_ATTENTION_SCORES=eager|flash runs the model-level parity tests under the other attention numerics (the gate of
+    DESIGN §4 "Attention, round 4": both settings are held to the same fixtures); unset = the model's default"""
+    v = os.environ.get("MJV_TEST_ATTENTION_SCORES")
+    if v:
+        assert v in ("eager", "flash")
+        model.attention_scores = v
+    return model
+
+
 def build_hip_model(cfg, sd, device):
     from mj_video_amd.modeling import InternVLChatRewardModeling
     model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16)
@@ -45,7 +55,7 @@ def build_hip_model(cfg, sd, device):
     model = model.to(torch.bfloat16).to(device)
     model.model.img_context_token_id = synth.IMG_CONTEXT_ID
     model.eval()
-    return model
+    return apply_test_overrides(model)
 
 
 def bf16_ulps(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -27,6 +27,7 @@ def run(name, n_seq, L, H, G, D, causal, mode):
     print(f"{name:12s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF/s", flush=True)
 
 
+MODE2 = bool(os.environ.get("MJV_ATTN_MODE2"))   # also time score_round_mode 2 (unrounded fp32 scores) next to the eager modes
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 variants = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 for rnd in range(rounds):
@@ -36,6 +37,11 @@ for rnd in range(rounds):
         run("vit_d64", 64, 1025, 16, 1, 64, False, 0)
         print("variant", v, end="  ")
         run("llm_d128", 8, 2186, 16, 2, 128, True, 1)
+        if MODE2 and v in (0, 6, 7):
+            print("variant", v, end="  "); run("vit_d64 m2", 64, 1025, 16, 1, 64, False, 2)
+            print("variant", v, end="  "); run("llm_d128 m2", 8, 2186, 16, 2, 128, True, 2)
+            print("variant", v, end="  "); run("d128c_28810 m1", 1, 28810, 16, 2, 128, True, 1)
+            print("variant", v, end="  "); run("d128c_28810 m2", 1, 28810, 16, 2, 128, True, 2)
         if len(sys.argv) > 4:
             print("variant", v, end="  "); run("d64_L1024", 64, 1024, 16, 1, 64, False, 0)
             print("variant", v, end="  "); run("d128_L2048", 8, 2048, 16, 2, 128, False, 1)
