@@ -199,6 +199,8 @@ def main():
     model.eval()
     if args.fp8:
         model.set_ffn_format("mxfp8")
+    if os.environ.get("MJV_BENCH_NORM_FUSION"):   # A/B of DESIGN "Norm fusion, round 4" (never a reported headline: the line says so)
+        model.norm_fusion = True
     for code in args.gemm_code:   # (bench build of the library only: MJV_LIBRARY=.../libmjv_hip_bench.so)
         ops.gemm_set_tile(code)
 
@@ -281,7 +283,8 @@ def main():
             "vs_baseline": None,
             "dtype": ("fp8-e4m3 (MXFP8, block-32 e8m0 scales) operands + fp32 accumulate in the FFN GEMMs, bf16 elsewhere"
                       if args.fp8 else "bf16"),
-            "data": "synthetic", "ranks_seen": ranks_seen,
+            "data": "synthetic", "ranks_seen": ranks_seen, "norm_fusion": bool(model.norm_fusion),
+            "attention_scores": model.attention_scores,
             "process_group": ("nccl" if use_dist else None),
             "config": {"workload": (f"MJ-VIDEO-2B, batch={args.pairs * world} pairs"
                                     + (f" sharded DP over {world} MI355X ({args.pairs} pairs per GPU), RCCL all-gather rewards"

@@ -132,6 +132,19 @@ typedef struct mjv_gemm_desc {
   int32_t a_format, w_format, c_format;
   const uint8_t *a_scales, *w_scales;
   uint8_t* c_scales;
+  /* ---- ABI 5: a norm folded into this GEMM (north_star "RMSNorm / LayerNorm -> GEMM fusion"; bf16 operands) ----
+   * The Linear's value before its bf16 rounding becomes   row_scale[m] * acc - row_shift[m] * col_shift[n] + bias_f32[n]
+   * (row_shift / col_shift / bias_f32 all NULL: row_scale[m] * acc + bias[n]).  With A = the UN-normalised rows x and
+   * W' = W * gain (folded once), row_scale = rstd, row_shift = mean * rstd, col_shift[n] = sum_k W'[n][k],
+   * bias_f32 = bias + W beta this is Linear(LayerNorm(x)) (modeling_intern_vit.py:291-293) / Linear(RMSNorm(x))
+   * (modeling_internlm2.py:138-143,653,669) without the normalised rows ever reaching HBM; mjv_row_stats_bf16 writes the two
+   * row vectors.  Rounding points DIFFER from the reference's (no bf16 rounding of the normalised rows, the gain rounded into
+   * W'): opt-in, behind model.norm_fusion, judged by the fixtures (DESIGN "Norm fusion, round 4").
+   * fp32 vectors, 16-byte aligned; row vectors readable up to ceil(M / 256) * 256 entries, column vectors up to
+   * ceil(N / 256) * 256 (the 256-tile kernel fetches whole tiles of them by LDS-DMA).  Not with MJV_EPI_SCALE_RES.  The
+   * 256-tile kernel instantiates BIAS / BIAS_GELU with a folded LayerNorm and SILU_MUL / ROPE_QKV with a folded RMSNorm (the
+   * model's four call sites); every other combination runs on the small-tile kernels or returns MJV_E_UNSUPPORTED. */
+  const float *row_scale, *row_shift, *col_shift, *bias_f32;
 } mjv_gemm_desc;
 
 /* a workspace of this size is enough for every problem shape (256 partial 256x256 fp32 tiles = 64 MiB) */
@@ -193,6 +206,12 @@ int mjv_layernorm_mxfp8(const mjv_bf16* x, int64_t ldx, uint8_t* y, int64_t ldy,
                         const mjv_bf16* beta, int32_t rows, int32_t dim, float eps, void* stream);
 int mjv_rmsnorm_mxfp8(const mjv_bf16* x, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* y_scales, const mjv_bf16* w,
                       int32_t rows, int32_t dim, float eps, void* stream);
+
+/* Row statistics of a norm that is folded into the consuming GEMM (mjv_gemm_desc.row_scale): one pass over x,
+ * rstd[m] = rsqrt(var + eps) with var = mean((x - mean)^2) (LayerNorm) or mean(x^2) (mean_rstd == NULL: RMSNorm),
+ * mean_rstd[m] = mean * rstd.  8 bytes written per row instead of the normalised row. */
+int mjv_row_stats_bf16(const mjv_bf16* x, int64_t ldx, float* rstd, float* mean_rstd, int32_t rows, int32_t dim, float eps,
+                       void* stream);
 
 /* GQA de-interleave + rotary embedding (modeling_internlm2.py:361-381,233-247):
  * qkv [rows][kv_heads * (group + 2) * 128] -> q [rows][kv_heads*group*128], k [rows][kv_heads*128], both rotated

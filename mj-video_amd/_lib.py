@@ -37,7 +37,9 @@ class GemmDesc(C.Structure):
                 ("rope_ldk", C.c_int64), ("rope_group", C.c_int32),
                 # ABI 5: operand / output formats (all zero = bf16)
                 ("a_format", C.c_int32), ("w_format", C.c_int32), ("c_format", C.c_int32),
-                ("a_scales", C.c_void_p), ("w_scales", C.c_void_p), ("c_scales", C.c_void_p)]
+                ("a_scales", C.c_void_p), ("w_scales", C.c_void_p), ("c_scales", C.c_void_p),
+                # ABI 5: a norm folded into the GEMM (fp32 vectors)
+                ("row_scale", C.c_void_p), ("row_shift", C.c_void_p), ("col_shift", C.c_void_p), ("bias_f32", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -77,6 +79,7 @@ SYMBOLS = {
     "mjv_quantize_mxfp8": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _I32, _I32, _VP]),
     "mjv_layernorm_mxfp8": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _I32, _I32, _F, _VP]),
     "mjv_rmsnorm_mxfp8": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, _F, _VP]),
+    "mjv_row_stats_bf16": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _I32, _F, _VP]),
     "mjv_rope_split_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "mjv_patchify_bf16": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _VP]),
     "mjv_cls_rows_bf16": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _I32, _I32, _VP]),

@@ -75,6 +75,8 @@ struct GemmArgs {
   u16 *rope_q, *rope_k;
   long rope_ldq, rope_ldk;
   int rope_group;
+  // norm folded into the consumer (mjv.h "row_scale"): lin = row_scale[m] * acc - row_shift[m] * col_shift[n] + bias
+  const float *row_scale, *row_shift, *col_shift, *bias_f32;
 };
 
 // x * rcp(1 + e^-x): v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division; the result is rounded to bf16 next, and
@@ -97,10 +99,10 @@ MJV_DEV long out_row_of(const GemmArgs& p, int m) {
 }
 
 // SiLU-mul: gate fragment (weight rows n..n+3 of a w1 block) and the matching up fragment (w3 block)
-MJV_DEV void store_silu(const GemmArgs& p, const f32x4& g, const f32x4& u, long orow, int oc) {
+MJV_DEV void store_silu(const GemmArgs& p, const f32x4& g, const f32x4& u, long orow, int oc, float rs = 1.f) {
   float o[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = rbf(silu(rbf(g[r]))) * rbf(u[r]);
+  for (int r = 0; r < 4; ++r) o[r] = rbf(silu(rbf(g[r] * rs))) * rbf(u[r] * rs);
   const u32x2 v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
   *(u32x2*)(p.C + orow * p.ldc + oc) = v;
 }
@@ -136,6 +138,23 @@ MJV_DEV void store_frags(const GemmArgs& p, const f32x4* acc /* [NI][NJ] */, con
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bb[j] = *(const u32x2*)(p.bias + nc[j]);
   }
+  // norm folded into this GEMM: lin = row_scale[m] acc - row_shift[m] col_shift[n] + bias_f32[n] (uniform branches)
+  float rsc[NI], rsh[NI];
+  f32x4 csh[NJ], bf[NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { rsc[i] = 1.f; rsh[i] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) csh[j] = bf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.row_scale) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) rsc[i] = p.row_scale[mc[i]];
+    if (p.row_shift) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) rsh[i] = p.row_shift[mc[i]];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { csh[j] = *(const f32x4*)(p.col_shift + nc[j]); bf[j] = *(const f32x4*)(p.bias_f32 + nc[j]); }
+    }
+  }
   if constexpr (EPI == MJV_EPI_SCALE_RES) {
     if (p.scale) {
 #pragma unroll
@@ -156,6 +175,10 @@ MJV_DEV void store_frags(const GemmArgs& p, const f32x4* acc /* [NI][NJ] */, con
       if (ncol[j] >= p.N) continue;
       const f32x4 a = acc[i * NJ + j];
       float v[4] = {a[0], a[1], a[2], a[3]};
+      if (p.row_scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], rsc[i], fmaf(-rsh[i], csh[j][r], bf[j][r]));
+      }
       if (p.bias) {
         v[0] += __uint_as_float(bb[j][0] << 16);
         v[1] += __uint_as_float(bb[j][0] & 0xffff0000u);
@@ -308,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
       for (int j = 0; j < 4; j += 2) {
         const int n = n0 + wn * 64 + j * 16 + l4 * 4;
         if (n >= p.N) continue;
-        store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4);
+        store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4,
+                   p.row_scale ? p.row_scale[p.m_base + mrel] : 1.f);
       }
     }
   } else {
@@ -354,7 +378,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p) {
       for (int j = 0; j < 4; j += 2) {
         const int n = n0 + wn * 64 + j * 16 + l4 * 4;
         if (n >= p.N) continue;
-        store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4);
+        store_silu(p, acc[i][j], acc[i][j + 1], orow, (n0 + wn * 64) / 2 + (j / 2) * 16 + l4 * 4,
+                   p.row_scale ? p.row_scale[p.m_base + mrel] : 1.f);
       }
     }
   } else {
@@ -463,7 +488,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NJ; j += 2) {
       const int n = n0 + j * 16 + l4 * 4;
-      if (n < p.N) store_silu(p, acc[j], acc[j + 1], orow, n0 / 2 + (j / 2) * 16 + l4 * 4);
+      if (n < p.N) store_silu(p, acc[j], acc[j + 1], orow, n0 / 2 + (j / 2) * 16 + l4 * 4, p.row_scale ? p.row_scale[p.m_base + mrel] : 1.f);
     }
   } else {
     const int mr[1] = {mrel};
@@ -485,6 +510,12 @@ constexpr int EPI_TILE_BYTES = 256 * EPI_PITCH;
 constexpr int GELU_BYTES = MJV_GELU_TABLE_LEN * 2;
 constexpr int LDS_BYTES = EPI_TILE_BYTES + GELU_BYTES;  // 140704 B >= PIPE_BYTES: one workgroup per CU either way
 static_assert(LDS_BYTES >= PIPE_BYTES && LDS_BYTES <= 160 * 1024 && EPI_TILE_BYTES % 16 == 0, "LDS budget");
+// FUSE kernels (a norm folded into this GEMM, mjv.h "row_scale"): the tile's 256 row_scale / row_shift / col_shift / bias_f32
+// floats, 1 KiB each, past the GELU table - fetched by LDS-DMA in the prologue (older than every K-tile DMA the counted waits
+// count), read in pass A: no register lives through the main loop for them
+constexpr int ST_OFF = LDS_BYTES;
+constexpr int LDS_BYTES_FUSE = LDS_BYTES + 4096;
+static_assert(ST_OFF % 16 == 0 && LDS_BYTES_FUSE <= 160 * 1024, "LDS budget (fused norm)");
 
 // per-lane global source pointers of the two 1-KiB DMA pieces a wave issues for each of the four half-tiles
 // (W rows 0-127, W rows 128-255, A rows 0-127, A rows 128-255) at k = 0: the row clamp and the chunk swizzle are loop
@@ -543,7 +574,16 @@ MJV_DEV void stage_half(const StagePtrs& sp, int t, int nk, char* smem, int wave
 // wait also waits for the epilogue's stores); a role-split persistent form where 4 waves issue all DMA and the other 4
 // all global stores (-5...-35 %: spills + half-width pass B); touching the residual tile's 1024 cache lines (one dword each)
 // three K-tiles before the end of the main loop so that pass B finds it in L2 (round 2: neutral on proj / fc2 / wo / w2).
-template <int EPI, int VAR>
+// FUSE: 0 = plain; 1 = lin = row_scale[m] * acc (+ bias): an RMSNorm folded into this GEMM (gain in W, rstd here);
+// 2 = lin = row_scale[m] * acc - row_shift[m] * col_shift[n] + bias_f32[n]: a LayerNorm folded into it
+MJV_DEV void stage_fused_vectors(const GemmArgs& p, int fuse, int m0, int n0, char* smem, int wave, int lane, int st_off) {
+  if (wave >= (fuse == 2 ? 4 : 1)) return;
+  const float* src = wave == 0 ? p.row_scale + p.m_base + m0 : wave == 1 ? p.row_shift + p.m_base + m0 : wave == 2 ? p.col_shift + n0 : p.bias_f32 + n0;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 4),
+                                   (__attribute__((address_space(3))) void*)(smem + st_off + wave * 1024), 16, 0, 0);
+}
+
+template <int EPI, int VAR, int FUSE = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -645,6 +685,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) sp.src[which][i] += kt0 * BK;
   }
+  if constexpr (FUSE != 0) stage_fused_vectors(p, FUSE, m0, n0, smem, wave, lane, ST_OFF);
   // ---- prologue: K-tile 0 completely, W halves of K-tile 1
   stage_half<0>(sp, 0, nk, smem, wave);
   stage_half<1>(sp, 0, nk, smem, wave);
@@ -797,12 +838,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       }
     }
   }
+  // FUSE: this lane's eight rows' row_scale (and row_shift) out of the LDS copy; the Linear's value before its rounding is
+  // lin(i, j, r) = acc * rs[i] + bq[r], bq = bias - row_shift[i] * col_shift (one more fma per element for a LayerNorm)
+  float rs8[FUSE ? 8 : 1], rh8[FUSE == 2 ? 8 : 1];
+  if constexpr (FUSE != 0) {
+    const float* st = (const float*)(smem + ST_OFF);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rs8[i] = st[wr * 128 + i * 16 + l15];
+    if constexpr (FUSE == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rh8[i] = st[256 + wr * 128 + i * 16 + l15];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int nl = wc * 64 + j * 16 + l4 * 4;   // column inside the 256-wide weight tile
     const u32x2 bb = braw[j];
-    const float b4[4] = {__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
-                         __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+    float b4[4] = {__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                   __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+    f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FUSE == 2) {
+      const f32x4 bq = *(const f32x4*)(smem + ST_OFF + 3072 + nl * 4);
+      c4 = *(const f32x4*)(smem + ST_OFF + 2048 + nl * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b4[r] = bq[r];
+    }
+    auto lin = [&](int i, int jj, int r) __attribute__((always_inline)) -> float {
+      if constexpr (FUSE == 0) return acc[i][jj][r] + b4[r];
+      else if constexpr (FUSE == 1) return fmaf(acc[i][jj][r], rs8[i], b4[r]);
+      else return fmaf(acc[i][jj][r], rs8[i], fmaf(-rh8[i], c4[r], b4[r]));
+    };
     if (EPI == MJV_EPI_SILU_MUL && (j & 1)) continue;
     if constexpr (EPI == MJV_EPI_BIAS_GELU) {
       // GELU by table, a whole column group (8 fragments = 32 elements per lane) at a time: the indices of all 32 first, ONE
@@ -817,7 +882,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          ubs[i][r] = __float_as_uint(rbf(acc[i][j][r] + b4[r]));
+          ubs[i][r] = __float_as_uint(rbf(lin(i, j, r)));
           const unsigned rel = ((ubs[i][r] >> 16) & 0x7fffu) - MJV_GELU_LO;
           all_in = all_in && (rel < (unsigned)MJV_GELU_R);
           idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_R;
@@ -854,12 +919,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       float v[4];
       int col;
       if constexpr (EPI == MJV_EPI_SILU_MUL) {
+        const float rs = FUSE ? rs8[i] : 1.f;   // (no bias on this epilogue: the folded RMSNorm is the row factor alone)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(silu(rbf(acc[i][j][r]))) * rbf(acc[i][j + 1][r]);
+        for (int r = 0; r < 4; ++r) v[r] = rbf(silu(rbf(FUSE ? acc[i][j][r] * rs : acc[i][j][r]))) * rbf(FUSE ? acc[i][j + 1][r] * rs : acc[i][j + 1][r]);
         col = wc * 32 + (j >> 1) * 16 + l4 * 4;
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + b4[r];
+        for (int r = 0; r < 4; ++r) v[r] = lin(i, j, r);
         if constexpr (EPI == MJV_EPI_BIAS_RELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -1013,7 +1079,7 @@ __global__ __launch_bounds__(512) void splitk_finish256_kernel(GemmArgs p) {
     for (int j = 0; j < 4; j += 2) {
       const int n = n0 + wc * 64 + j * 16 + l4 * 4;
       if (n >= p.N) continue;
-      store_silu(p, fr[j], fr[j + 1], orow, n0 / 2 + wc * 32 + (j / 2) * 16 + l4 * 4);
+      store_silu(p, fr[j], fr[j + 1], orow, n0 / 2 + wc * 32 + (j / 2) * 16 + l4 * 4, p.row_scale ? p.row_scale[p.m_base + mrel] : 1.f);
     }
   } else {
     const int mr[1] = {mrel};
@@ -1042,7 +1108,13 @@ constexpr int EPI_WIN_OFF = 4 * HALF_BYTES;                           // = pipel
 constexpr int GELU_OFF_P = EPI_WIN_OFF + EPI_HALF_BYTES;              // the table sits past the window, untouched by the loops
 static_assert(GELU_OFF_P + GELU_BYTES <= LDS_BYTES, "persistent layout fits the kernel's LDS allocation");
 
-template <int EPI>
+// FUSE (see gemm256_kernel): the tile's row / column vectors go to one of TWO 4-KiB LDS areas (tile parity): those of the NEXT
+// tile are requested just before its prefetched K-tile 0 - older in the queue than everything the counted waits leave in flight -
+// while the current tile's pass A still reads its own.
+constexpr int LDS_BYTES_FUSE_P = LDS_BYTES + 8192;
+static_assert(LDS_BYTES_FUSE_P <= 160 * 1024, "LDS budget (fused norm, persistent)");
+
+template <int EPI, int FUSE = 0>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1084,11 +1156,16 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
 
   bool prefetched = false;
   int stores_behind = 0;   // store instructions this wave issued after the prefetch of the tile about to start (a lower bound)
+  int st_par = 0;          // which of the two vector areas the current tile uses (FUSE)
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     int tm, tn;
     tile_of_vblock(p, n_tiles, tile, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    const int st_off = ST_OFF + st_par * 4096;
+    if constexpr (FUSE != 0) {
+      if (!prefetched) stage_fused_vectors(p, FUSE, m0, n0, smem, wave, lane, st_off);   // (first tile of this workgroup)
+    }
     StagePtrs sp;   // (recomputed per tile: cheaper than 16 registers carried through the epilogue)
     init_stage_ptrs(sp, p, m0, n0, wave, lane);
     const int nout0 = (EPI == MJV_EPI_SILU_MUL) ? n0 / 2 : n0;
@@ -1239,6 +1316,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
       tile_of_vblock(p, n_tiles, next, tm2, tn2);
       StagePtrs sp_next;
       init_stage_ptrs(sp_next, p, tm2 * BM, tn2 * BN, wave, lane);
+      if constexpr (FUSE != 0) stage_fused_vectors(p, FUSE, tm2 * BM, tn2 * BN, smem, wave, lane, ST_OFF + (st_par ^ 1) * 4096);
       stage_half<0>(sp_next, 0, nk, smem, wave);
       stage_half<1>(sp_next, 0, nk, smem, wave);
       stage_half<2>(sp_next, 0, nk, smem, wave);
@@ -1247,6 +1325,16 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     }
 
     // ---- epilogue in two row halves through the window over set 1
+    float rs8[FUSE ? 8 : 1], rh8[FUSE == 2 ? 8 : 1];
+    if constexpr (FUSE != 0) {
+      const float* st = (const float*)(smem + st_off);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rs8[i] = st[wr * 128 + i * 16 + l15];
+      if constexpr (FUSE == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rh8[i] = st[256 + wr * 128 + i * 16 + l15];
+      }
+    }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       {   // pass A by all eight waves: each wave's fragments 4 hf .. 4 hf + 3 (its rows 64 hf .. 64 hf + 63) -> window rows 64 wr ..
@@ -1254,8 +1342,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
           const int nl = wc * 64 + j * 16 + l4 * 4;
           const u32x2 bb = braw[j];
-          const float b4[4] = {__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
-                               __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+          float b4[4] = {__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                         __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+          f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (FUSE == 2) {
+            const f32x4 bq = *(const f32x4*)(smem + st_off + 3072 + nl * 4);
+            c4 = *(const f32x4*)(smem + st_off + 2048 + nl * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = bq[r];
+          }
+          auto lin = [&](int i, int jj, int r) __attribute__((always_inline)) -> float {   // i = fragment 0 .. 7 of the wave
+            if constexpr (FUSE == 0) return acc[i][jj][r] + b4[r];
+            else if constexpr (FUSE == 1) return fmaf(acc[i][jj][r], rs8[i], b4[r]);
+            else return fmaf(acc[i][jj][r], rs8[i], fmaf(-rh8[i], c4[r], b4[r]));
+          };
           if (EPI == MJV_EPI_SILU_MUL && (j & 1)) continue;
           if constexpr (EPI == MJV_EPI_BIAS_GELU) {
             unsigned ubs[4][4], idx[4][4];
@@ -1264,7 +1364,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                ubs[i][r] = __float_as_uint(rbf(acc[4 * hf + i][j][r] + b4[r]));
+                ubs[i][r] = __float_as_uint(rbf(lin(4 * hf + i, j, r)));
                 const unsigned rel = ((ubs[i][r] >> 16) & 0x7fffu) - MJV_GELU_LO;
                 all_in = all_in && (rel < (unsigned)MJV_GELU_R);
                 idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_R;
@@ -1297,12 +1397,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
             float v[4];
             int col;
             if constexpr (EPI == MJV_EPI_SILU_MUL) {
+              const float rs = FUSE ? rs8[4 * hf + i] : 1.f;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = rbf(silu(rbf(acc[4 * hf + i][j][r]))) * rbf(acc[4 * hf + i][j + 1][r]);
+              for (int r = 0; r < 4; ++r)
+                v[r] = rbf(silu(rbf(FUSE ? acc[4 * hf + i][j][r] * rs : acc[4 * hf + i][j][r]))) *
+                       rbf(FUSE ? acc[4 * hf + i][j + 1][r] * rs : acc[4 * hf + i][j + 1][r]);
               col = wc * 32 + (j >> 1) * 16 + l4 * 4;
             } else {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = acc[4 * hf + i][j][r] + b4[r];
+              for (int r = 0; r < 4; ++r) v[r] = lin(4 * hf + i, j, r);
               if constexpr (EPI == MJV_EPI_BIAS_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -1342,6 +1445,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
       }
       __syncthreads();   // the window is rewritten by the next half / refilled by the next tile's K-tile 1
     }
+    st_par ^= 1;
   }
 }
 
@@ -1398,7 +1502,42 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<MJV_EPI_BIAS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     if constexpr (EPI != MJV_EPI_ROPE_QKV)
       (void)hipFuncSetAttribute((const void*)t256::gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+    // a norm folded into the GEMM: LayerNorm into the ViT's qkv / fc1 (bias epilogues), RMSNorm into wqkv / w1|w3
+    if constexpr (EPI == MJV_EPI_BIAS || EPI == MJV_EPI_BIAS_GELU)
+      (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES_FUSE);
+    if constexpr (EPI == MJV_EPI_SILU_MUL || EPI == MJV_EPI_ROPE_QKV)
+      (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES_FUSE);
+    if constexpr (EPI == MJV_EPI_BIAS)
+      (void)hipFuncSetAttribute((const void*)t256::gemm256p_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES_FUSE_P);
+    if constexpr (EPI == MJV_EPI_SILU_MUL)
+      (void)hipFuncSetAttribute((const void*)t256::gemm256p_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES_FUSE_P);
     attr_done.fetch_or(bit, std::memory_order_release);   // racing first calls both set the attributes: idempotent
+  }
+  const int fuse = a.row_scale ? (a.row_shift ? 2 : 1) : 0;
+  if (big && a.split <= 1 && fuse) {
+    // the 256 x 256 kernels instantiate the folded-norm epilogue where the model uses it; the small kernels and the K-sliced
+    // finish take every combination (store_frags)
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    const int tiles = a.tiles_m * a.tiles_n, nk = a.K / 64;
+    const bool persistent = tiles > g_num_cus && nk >= 4 && (nk & 1) == 0;
+    constexpr int WANT = (EPI == MJV_EPI_BIAS || EPI == MJV_EPI_BIAS_GELU) ? 2 : (EPI == MJV_EPI_SILU_MUL || EPI == MJV_EPI_ROPE_QKV) ? 1 : 0;
+    if constexpr (WANT != 0) {
+      if (fuse == WANT) {
+        if constexpr (EPI == MJV_EPI_BIAS || EPI == MJV_EPI_SILU_MUL) {
+          if (persistent) {
+            hipLaunchKernelGGL((t256::gemm256p_kernel<EPI, WANT>), dim3(g_num_cus), dim3(512), t256::LDS_BYTES_FUSE_P, s, a);
+            return mjv_check_launch("gemm_bf16");
+          }
+        }
+        hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0, WANT>), dim3(tiles), dim3(512), t256::LDS_BYTES_FUSE, s, a);
+        return mjv_check_launch("gemm_bf16");
+      }
+    }
+    mjv_set_error("gemm: the 256-tile kernel has no instantiation for epilogue %d with %s folded in (bias / bias+GELU take a "
+                  "LayerNorm: row_scale + row_shift; SiLU-mul / RoPE-qkv an RMSNorm: row_scale only)", (int)EPI,
+                  fuse == 2 ? "row_scale + row_shift" : "row_scale");
+    return MJV_E_UNSUPPORTED;
   }
   if (big) {
     a.tiles_m = (a.M + 255) / 256;
@@ -1524,6 +1663,17 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   a.gm = MJV_TUNE(gm) > 0 ? MJV_TUNE(gm) : pick_gm(d->N, d->K);
   a.rope_cos = d->rope_cos; a.rope_sin = d->rope_sin; a.rope_pos = d->rope_pos; a.rope_q = d->rope_q; a.rope_k = d->rope_k;
   a.rope_ldq = d->rope_ldq; a.rope_ldk = d->rope_ldk; a.rope_group = d->rope_group;
+  a.row_scale = d->row_scale; a.row_shift = d->row_shift; a.col_shift = d->col_shift; a.bias_f32 = d->bias_f32;
+  if (d->row_scale) {
+    MJV_REQUIRE((d->row_shift != nullptr) == (d->col_shift != nullptr) && (d->row_shift != nullptr) == (d->bias_f32 != nullptr),
+                "gemm: row_shift, col_shift and bias_f32 go together (a folded LayerNorm) or not at all (a folded RMSNorm)");
+    MJV_REQUIRE(!d->row_shift || !d->bias, "gemm: a folded LayerNorm carries its bias in bias_f32");
+    MJV_REQUIRE(d->epilogue != MJV_EPI_SCALE_RES, "gemm: no norm is folded into the residual epilogue");
+    MJV_REQUIRE(((uintptr_t)d->row_scale | (uintptr_t)d->row_shift | (uintptr_t)d->col_shift | (uintptr_t)d->bias_f32) % 16 == 0,
+                "gemm: row / column vectors must be 16-byte aligned");
+  } else {
+    MJV_REQUIRE(!d->row_shift && !d->col_shift && !d->bias_f32, "gemm: row_shift / col_shift / bias_f32 need row_scale");
+  }
   a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;
   const bool big = force_tile ? force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;

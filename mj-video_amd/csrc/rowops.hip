@@ -145,6 +145,52 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const u16* __restrict__ x,
   }
 }
 
+// ------------------------------------------------------------------------------------------ row statistics
+// The producer half of a norm folded into its consuming GEMM (mjv.h "row_scale"): the same fp32 statistics as the kernels
+// above - two-pass mean / biased variance (LayerNorm) or the mean square (RMSNorm, MEAN = false) - and nothing else: 2 B read
+// per element, 8 B written per row.
+template <int IT, bool MEAN>
+__global__ __launch_bounds__(256) void row_stats_kernel(const u16* __restrict__ x, long ldx, float* __restrict__ rstd,
+                                                        float* __restrict__ mean_rstd, int rows, int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[IT][8];
+  float sum = 0.f, sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int c = it * 512 + lane * 8;
+    if (c < dim) {
+      unpack8(*(const u32x4*)(x + (long)row * ldx + c), v[it]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (MEAN) sum += v[it][j];
+        else sq += v[it][j] * v[it][j];
+      }
+    }
+  }
+  float mean = 0.f;
+  if constexpr (MEAN) {
+    mean = wave_sum(sum) / (float)dim;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int c = it * 512 + lane * 8;
+      if (c < dim) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[it][j] - mean;
+          sq += d * d;
+        }
+      }
+    }
+  }
+  const float r = rsqrtf(wave_sum(sq) / (float)dim + eps);
+  if (lane == 0) {
+    rstd[row] = r;
+    if constexpr (MEAN) mean_rstd[row] = mean * r;
+  }
+}
+
 // ------------------------------------------------------------------------------- RoPE + GQA de-interleave
 // wqkv output columns are (kv_head, [q_0 .. q_{g-1}, k, v], 128)  (modeling_internlm2.py:361-371).
 // q' = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)) with bf16 tables (modeling_internlm2.py:240-247).
@@ -255,6 +301,26 @@ extern "C" int mjv_rmsnorm_bf16(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int
   else
     hipLaunchKernelGGL(rmsnorm_kernel<MAX_IT>, grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w, row_index, rows, dim, eps);
   return mjv_check_launch("rmsnorm");
+}
+
+extern "C" int mjv_row_stats_bf16(const mjv_bf16* x, int64_t ldx, float* rstd, float* mean_rstd, int32_t rows, int32_t dim, float eps,
+                                  void* stream) {
+  MJV_REQUIRE(x && rstd, "row_stats: null pointer");
+  MJV_REQUIRE(rows > 0 && dim > 0 && dim % 8 == 0 && dim <= 512 * MAX_IT, "row_stats: dim %d unsupported", dim);
+  MJV_REQUIRE(ldx % 8 == 0, "row_stats: ld alignment");
+  hipStream_t s = (hipStream_t)stream;
+  MjvProfScope ps(mean_rstd ? "row_stats_ln" : "row_stats_rms", s, 0, 2.0 * rows * (double)dim);
+  const dim3 grid((rows + WAVES - 1) / WAVES);
+#define MJV_RS(IT)                                                                                                               \
+  do {                                                                                                                           \
+    if (mean_rstd) hipLaunchKernelGGL((row_stats_kernel<IT, true>), grid, dim3(256), 0, s, x, (long)ldx, rstd, mean_rstd, rows, dim, eps); \
+    else hipLaunchKernelGGL((row_stats_kernel<IT, false>), grid, dim3(256), 0, s, x, (long)ldx, rstd, mean_rstd, rows, dim, eps);         \
+  } while (0)
+  if (dim <= 1024) MJV_RS(2);
+  else if (dim <= 2048) MJV_RS(4);
+  else MJV_RS(MAX_IT);
+#undef MJV_RS
+  return mjv_check_launch("row_stats");
 }
 
 extern "C" int mjv_layernorm_mxfp8(const mjv_bf16* x, int64_t ldx, uint8_t* y, int64_t ldy, uint8_t* y_scales, const mjv_bf16* gamma,

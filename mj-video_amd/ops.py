@@ -146,12 +146,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, res_mod: int = 0, res_off: int = 0, out_group: int = 0,
          out_pad: int = 0, out_rows: Optional[torch.Tensor] = None, M: Optional[int] = None,
-         rope: Optional[tuple] = None, workspace: Optional[torch.Tensor] = None, tile: Optional[int] = None) -> torch.Tensor:
+         rope: Optional[tuple] = None, workspace: Optional[torch.Tensor] = None, tile: Optional[int] = None,
+         folded_norm: Optional[tuple] = None) -> torch.Tensor:
     """out = epilogue(a[M,K] @ w[N,K]^T); 2-D row-contiguous bf16 views (row strides are honoured).
     ``rope`` (EPI_ROPE_QKV only) = (cos, sin, positions, q_out, k_out, group): see include/mjv.h.
     ``workspace``: split-K scratch of THIS call (default: the calling thread's ``set_gemm_workspace`` buffer);
     ``tile``: 0 automatic, 64 / 128 / 256 force one tile kernel (default: the calling thread's ``gemm_set_tile`` value).
-    ``a`` and ``w`` may be ``MX8`` (MXFP8 operands, ABI 5), ``out`` then a bf16 tensor or an ``MX8``."""
+    ``a`` and ``w`` may be ``MX8`` (MXFP8 operands, ABI 5), ``out`` then a bf16 tensor or an ``MX8``.
+    ``folded_norm`` = (row_scale,) or (row_scale, row_shift, col_shift, bias_f32): fp32 vectors of a norm folded into this GEMM
+    (include/mjv.h "row_scale"; row vectors of ``padded_rows(M)`` entries from ``row_stats``, column vectors of
+    ``padded_rows(N)``)."""
     if isinstance(a, MX8):
         assert res_mod == 0 and out_group == 0 and out_rows is None and rope is None, "MXFP8 GEMMs write plain rows"
         return _gemm_mxfp8(a, w, out, epilogue, bias, scale, res, M)
@@ -179,6 +183,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         d.rope_cos, d.rope_sin, d.rope_pos = cos.data_ptr(), sin.data_ptr(), positions.data_ptr()
         d.rope_q, d.rope_k = q_out.data_ptr(), k_out.data_ptr()
         d.rope_ldq, d.rope_ldk, d.rope_group = _row_stride(q_out), _row_stride(k_out), group
+    if folded_norm is not None:
+        for t, n in zip(folded_norm, (d.M, d.M, d.N, d.N)):
+            assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous() and t.numel() >= padded_rows(n), (t.shape, n)
+        d.row_scale = folded_norm[0].data_ptr()
+        if len(folded_norm) == 4:
+            d.row_shift, d.col_shift, d.bias_f32 = (t.data_ptr() for t in folded_norm[1:])
+        else:
+            assert len(folded_norm) == 1
     ws = workspace if workspace is not None else _tls.gemm_ws
     if ws is not None and ws.device == a.device:
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
@@ -291,6 +303,22 @@ def rmsnorm_mxfp8(x: torch.Tensor, w: torch.Tensor, out: MX8, eps: float) -> MX8
                                                out.scales.data_ptr(), w.data_ptr(), x.shape[0], x.shape[1], eps, _stream(x)),
               "mjv_rmsnorm_mxfp8")
     return out
+
+
+def padded_rows(n: int) -> int:
+    """entries a row / column vector of a folded norm must hold for n rows / columns (whole 256-tiles are fetched)"""
+    return (n + 255) // 256 * 256
+
+
+def row_stats(x: torch.Tensor, rstd: torch.Tensor, mean_rstd: Optional[torch.Tensor], eps: float) -> None:
+    """rstd[m] (and mean[m] * rstd[m]: LayerNorm; None: RMSNorm statistics) of the rows of ``x`` - the producer half of a norm
+    folded into its consuming GEMM (``gemm(..., folded_norm=...)``)."""
+    _chk_bf16(x)
+    assert rstd.dtype == torch.float32 and rstd.is_cuda and rstd.numel() >= x.shape[0]
+    assert mean_rstd is None or (mean_rstd.dtype == torch.float32 and mean_rstd.numel() >= x.shape[0])
+    with torch.cuda.device(x.device):
+        check(load_library().mjv_row_stats_bf16(x.data_ptr(), _row_stride(x), rstd.data_ptr(), _p(mean_rstd), x.shape[0], x.shape[1],
+                                                eps, _stream(x)), "mjv_row_stats_bf16")
 
 
 def rope_split(qkv: torch.Tensor, q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,

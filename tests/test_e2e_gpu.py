@@ -103,8 +103,8 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-@pytest.mark.parametrize("scores", ["flash", "eager"])
-def test_tiny_cases_against_golden(cuda, scores):
+@pytest.mark.parametrize("scores,fused", [("flash", True), ("eager", False)])
+def test_tiny_cases_against_golden(cuda, scores, fused):
     """(both of the reference's attention numerics - model.attention_scores - against the same reference-executed fixtures)"""
     from mj_video_amd import synth
     npz, meta = load_golden("tiny")
@@ -116,6 +116,7 @@ def test_tiny_cases_against_golden(cuda, scores):
         sd = synth.synth_state_dict(cfg, seed=case["weight_seed"], dtype=torch.float32)
         model = build_hip_model(cfg, sd, cuda)
         model.attention_scores = scores
+        model.norm_fusion = fused
         px, ids, mask, _ = case_inputs(cfg, case["videos"], case["pixel_seed"], case["image_size"])
         model.debug_probes = {}
         out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
@@ -460,7 +461,8 @@ def _rank_case(cuda, name, pairs_per_forward):
     assert sep >= 0.999
 
 
-def test_last_layer_trimming_is_invisible(cuda):
+@pytest.mark.parametrize("fused", [False, True])
+def test_last_layer_trimming_is_invisible(cuda, fused):
     """production path (last decoder layer evaluated only on the 2 rows per sample the heads read) vs the full evaluation
     of every row (the debug-probe mode): every output field bit-identical at these shapes when both runs sum K in one
     order (K-slicing of under-filled GEMMs off: the 2 700-row full evaluation would otherwise run its K = 8192 GEMM as two
@@ -471,6 +473,7 @@ def test_last_layer_trimming_is_invisible(cuda):
     sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
         cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
     model = build_hip_model(cfg, sd, cuda)
+    model.norm_fusion = fused     # (norms folded into their GEMMs: the trimmed rows take the same folded form)
     vids = [dict(video_idx=i, n_tiles=t, caption_seed=i) for i, t in enumerate([8, 6, 8, 3, 5])]
     px, ids, mask, _ = case_inputs(cfg, vids, 77, 224)
     px, ids, mask = px.to(cuda), ids.to(cuda), mask.to(cuda)
@@ -528,9 +531,9 @@ def test_k_sliced_path_is_no_further_from_fp32(cuda):
         assert d_on <= 1.5 * d_ref and d_off <= 1.5 * d_ref, (f, d_on, d_off, d_ref)
 
 
-@pytest.mark.parametrize("scores", ["flash", "eager"])
+@pytest.mark.parametrize("scores,fused", [("flash", True), ("eager", False), ("flash", False)])
 @pytest.mark.parametrize("name", ["vit_layer0", "vit_layer23", "llm_layer0", "llm_layer23"])
-def test_single_layer_at_production_shape(cuda, name, scores):
+def test_single_layer_at_production_shape(cuda, name, scores, fused):
     """tests/golden/layers.npz: ONE layer at MJ-VIDEO-2B dimensions and the headline sequence lengths, executed by the
     reference's own InternVisionEncoderLayer.forward (modeling_intern_vit.py:283-295, [2, 1025, 1024]) /
     InternLM2DecoderLayer.forward (modeling_internlm2.py:621-681, [1, 2186, 2048]) on seed-defined bf16 rows with the
@@ -558,6 +561,7 @@ def test_single_layer_at_production_shape(cuda, name, scores):
     from util import apply_test_overrides
     model = apply_test_overrides(model.to(torch.bfloat16).to(cuda).eval())
     model.attention_scores = scores     # both of the reference's attention numerics are held to the same bound
+    model.norm_fusion = fused           # ... and the norms folded into their GEMMs (default) as well as the reference's rounding points
     x = layer_input_rows(m["input_seed"], case["input_tag"], tuple(case["shape"]))
     y = (model.run_vit_layer(0, x) if case["tower"] == "vit" else model.run_llm_layer(0, x)).float().cpu()
     rows = npz[f"{name}/rows"]
@@ -566,7 +570,7 @@ def test_single_layer_at_production_shape(cuda, name, scores):
     f32 = npz[f"{name}/fp32"]
     noise = case["ref_bf16_vs_fp32"]
     d_ref, d_f32 = rel_l2(got, ref), rel_l2(got, f32)
-    print(f"{name} [{scores} scores]: HIP vs reference bf16 {d_ref:.5f}, HIP vs reference fp32 {d_f32:.5f}; reference bf16 vs fp32 {noise:.5f}")
+    print(f"{name} [{scores} scores, norms {'folded' if fused else 'separate'}]: HIP vs reference bf16 {d_ref:.5f}, HIP vs reference fp32 {d_f32:.5f}; reference bf16 vs fp32 {noise:.5f}")
     assert np.isfinite(got).all()
     assert d_ref <= 2.0 * noise, (name, d_ref, noise)
     assert d_f32 <= 2.0 * noise, (name, d_f32, noise)

@@ -827,3 +827,126 @@ def test_randomised_sweep_of_gemm_and_attention(cuda):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
+
+
+# ------------------------------------------------------------------------------------------- norm folded into the GEMM
+def _pad256(v, cuda):
+    out = torch.zeros((v.numel() + 255) // 256 * 256, dtype=torch.float32, device=cuda)
+    out[:v.numel()] = v.to(cuda)
+    return out
+
+
+def test_row_stats(cuda):
+    from mj_video_amd import ops
+    for rows, dim in ((130, 128), (1025, 1024), (333, 2048), (70, 4096)):
+        x = (rnd(rows, dim, std=2.0, seed=3).float() + 0.7).to(BF)
+        rstd = torch.empty(ops.padded_rows(rows), dtype=torch.float32, device=cuda)
+        mrs = torch.empty_like(rstd)
+        ops.row_stats(x.to(cuda), rstd, mrs, 1e-6)
+        xd = x.double()
+        mean = xd.mean(1)
+        r = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-6)
+        assert torch.allclose(rstd[:rows].cpu().double(), r, rtol=2e-6, atol=0)
+        assert torch.allclose(mrs[:rows].cpu().double(), mean * r, rtol=2e-5, atol=1e-6)
+        ops.row_stats(x.to(cuda), rstd, None, 1e-5)
+        r2 = 1.0 / torch.sqrt((xd * xd).mean(1) + 1e-5)
+        assert torch.allclose(rstd[:rows].cpu().double(), r2, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K", [(515, 512, 256), (2200, 1024, 1024), (64, 256, 128)])
+def test_gemm_folded_layernorm(cuda, tile, M, N, K):
+    """Linear(LayerNorm(x)) with the norm folded into the GEMM (include/mjv.h "row_scale"): the kernel's Linear value is
+    rstd (x W'^T - mean colsum(W')) + bias' with W' = bf16(W gamma) - against that formula in fp64 (<= 1 bf16 ulp, GELU as
+    the unfused GELU test), and against the unfused composition LayerNorm -> Linear (different rounding points: relative L2)."""
+    from mj_video_amd import ops
+    x = (rnd(M, K, std=1.5, seed=1).float() + 0.4).to(BF)
+    gamma, beta = (rnd(K, std=0.2, seed=2).float() + 1.0).to(BF), rnd(K, std=0.2, seed=3)
+    w, b = rnd(N, K, std=0.05, seed=4), rnd(N, std=0.1, seed=5)
+    wf = (w.float() * gamma.float()[None, :]).to(BF)
+    colsum = wf.float().sum(1)
+    bias2 = w.float() @ beta.float() + b.float()
+    rstd = torch.empty(ops.padded_rows(M), dtype=torch.float32, device=cuda)
+    mrs = torch.empty_like(rstd)
+    xc = x.to(cuda)
+    ops.row_stats(xc, rstd, mrs, 1e-6)
+    fold = (rstd, mrs, _pad256(colsum, cuda), _pad256(bias2, cuda))
+    xd = x.double()
+    mean = xd.mean(1, keepdim=True)
+    r = 1.0 / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6)
+    lin = (r * (xd @ wf.double().t() - mean * colsum.double()[None, :]) + bias2.double()[None, :]).float()
+    out = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(xc, wf.to(cuda), out, ops.EPI_BIAS, folded_norm=fold)
+    # (the mean term cancels against the product: absolute floor = 2^-20 of the cancelling magnitudes)
+    atol = float((r * (xd.abs() @ wf.double().abs().t())).max()) * 2.0 ** -20
+    assert_close_bf16(out, lin.to(BF), 1, frac_exact=0.97, atol=atol, what="folded layernorm, bias")
+    ops.gemm(xc, wf.to(cuda), out, ops.EPI_BIAS_GELU, folded_norm=fold)
+    assert_close_bf16(out, F.gelu(lin.to(BF)), 3, frac_exact=0.96, atol=2e-3, what="folded layernorm, gelu")
+    # the unfused composition the reference computes: close, not equal (the normalised rows are never rounded here)
+    h = torch.empty(M, K, dtype=BF, device=cuda)
+    ops.layernorm(xc, gamma.to(cuda), beta.to(cuda), h, 1e-6)
+    ref = torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(h, w.to(cuda), ref, ops.EPI_BIAS, bias=b.to(cuda))
+    ops.gemm(xc, wf.to(cuda), out, ops.EPI_BIAS, folded_norm=fold)
+    rel = ((out.float() - ref.float()).norm() / ref.float().norm()).item()
+    assert rel < 6e-3, rel
+
+
+@pytest.mark.parametrize("M,K", [(515, 256), (2200, 2048), (80, 128)])
+def test_gemm_folded_rmsnorm(cuda, tile, M, K):
+    """Linear(RMSNorm(x)) folded: lin = rstd * (x W'^T), W' = bf16(W gain); SiLU-mul on interleaved w1 | w3 and the wqkv
+    epilogue (RoPE + GQA split; on the small tiles: plain Linear + rope_split) against fp64 of that formula"""
+    from mj_video_amd import ops
+    x = rnd(M, K, std=1.5, seed=1)
+    gain = (rnd(K, std=0.2, seed=2).float() + 1.0).to(BF)
+    xc = x.to(cuda)
+    rstd = torch.empty(ops.padded_rows(M), dtype=torch.float32, device=cuda)
+    ops.row_stats(xc, rstd, None, 1e-5)
+    xd = x.double()
+    r = 1.0 / torch.sqrt((xd * xd).mean(1, keepdim=True) + 1e-5)
+    ff = 256
+    # (unit-scale gate / up values: a gate of -5.7 on a bf16 rounding boundary flips by one ulp under any re-association and SiLU's
+    # negative tail turns that into 5 ulps of the product - seen once in 563 200 elements with sigma = 4.5)
+    w1, w3 = rnd(ff, K, std=1.5 / K ** 0.5, seed=6), rnd(ff, K, std=1.5 / K ** 0.5, seed=7)
+    w13 = torch.stack([w1.view(ff // 16, 16, K), w3.view(ff // 16, 16, K)], dim=1).reshape(2 * ff, K)
+    w13f = (w13.float() * gain.float()[None, :]).to(BF)
+    w1f, w3f = (w1.float() * gain.float()[None, :]).to(BF), (w3.float() * gain.float()[None, :]).to(BF)
+    g = (r * (xd @ w1f.double().t())).float().to(BF)
+    u = (r * (xd @ w3f.double().t())).float().to(BF)
+    ref = (F.silu(g.float()).to(BF).float() * u.float()).to(BF)
+    out = torch.empty(M, ff, dtype=BF, device=cuda)
+    ops.gemm(xc, w13f.to(cuda), out, ops.EPI_SILU_MUL, folded_norm=(rstd,))
+    assert_close_bf16(out, ref, 3, frac_exact=0.94, atol=2e-3, what="folded rmsnorm, silu_mul")
+    # wqkv: 1 kv group of (2 q heads + k + v) x 128 columns
+    G, N = 2, 512
+    wq = rnd(N, K, std=1.5 / K ** 0.5, seed=8)
+    wqf = (wq.float() * gain.float()[None, :]).to(BF)
+    lin = (r * (xd @ wqf.double().t())).float().to(BF)
+    pos = torch.arange(M, dtype=torch.int32) % 97
+    half = torch.arange(0, 128, 2).float() / 128
+    fr = torch.outer(torch.arange(100).float(), 1.0 / (10000.0 ** half))
+    emb = torch.cat([fr, fr], dim=-1)
+    cos, sin = emb.cos().to(BF).to(cuda).contiguous(), emb.sin().to(BF).to(cuda).contiguous()
+    qkv = torch.zeros(M, N, dtype=BF, device=cuda)
+    q, k = torch.empty(M, G * 128, dtype=BF, device=cuda), torch.empty(M, 128, dtype=BF, device=cuda)
+    ops.gemm(xc, wqf.to(cuda), qkv, ops.EPI_ROPE_QKV, rope=(cos, sin, pos.to(cuda), q, k, G), folded_norm=(rstd,))
+    q2, k2 = torch.empty_like(q), torch.empty_like(k)
+    ops.rope_split(lin.to(cuda), q2, k2, cos, sin, pos.to(cuda), 1, G)
+    # (a sum of 2048 products that cancels to ~1e-3 carries the fp32 summation-order difference of its 5-sigma terms)
+    assert_close_bf16(qkv[:, (G + 1) * 128:], lin[:, (G + 1) * 128:], 1, frac_exact=0.97, atol=1e-3, what="folded rmsnorm, v columns")
+    assert_close_bf16(q, q2, 2, frac_exact=0.95, atol=0.02, what="folded rmsnorm, rotated q")
+    assert_close_bf16(k, k2, 2, frac_exact=0.95, atol=0.02, what="folded rmsnorm, rotated k")
+
+
+def test_gemm_folded_norm_argument_errors(cuda):
+    from mj_video_amd import ops, _lib
+    x, w = rnd(300, 128).to(cuda), rnd(256, 128).to(cuda)
+    out = torch.empty(300, 256, dtype=BF, device=cuda)
+    rstd = torch.ones(512, dtype=torch.float32, device=cuda)
+    with pytest.raises(_lib.MjvLibraryError, match="residual"):
+        ops.gemm(x, w, out, ops.EPI_SCALE_RES, res=out, folded_norm=(rstd,))
+    with pytest.raises(_lib.MjvLibraryError, match="no instantiation"):
+        ops.gemm(x, w, out, ops.EPI_BIAS, folded_norm=(rstd,), tile=256)       # an RMSNorm into the plain-bias 256 kernel: not built
+    ops.gemm(x, w, out, ops.EPI_BIAS, folded_norm=(rstd,), tile=128)           # ... the small kernels take every combination
+    ref = torch.empty_like(out)
+    ops.gemm(x, w, ref, ops.EPI_BIAS, tile=128)
+    assert torch.equal(out, ref)                                               # row_scale = 1: the same Linear

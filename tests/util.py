@@ -44,6 +44,9 @@ def apply_test_overrides(model):
     if v:
         assert v in ("eager", "flash")
         model.attention_scores = v
+    nf = os.environ.get("MJV_TEST_NORM_FUSION")     # the gate of DESIGN "Norm fusion, round 4": same fixtures, "1" folded / "0" not
+    if nf:
+        model.norm_fusion = nf == "1"
     return model
 
 

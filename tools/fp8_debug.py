@@ -1,39 +1,28 @@
-"""How exact is the accumulation inside v_mfma_scale_f32_16x16x128_f8f6f4?  (diagnostic, tools only)"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.nn.functional as F
 from mj_video_amd import ops
-from oracle import ref_fp8
-BF = torch.bfloat16
-torch.manual_seed(0)
-for K in (128, 1024):
-    for astd, wstd in ((1.0, 0.05), (1.0, 1.0)):
-        M = N = 256
-        a = (torch.randn(M, K) * astd).to(BF); w = (torch.randn(N, K) * wstd).to(BF)
-        a8, w8 = ops.quantize_mxfp8(a.cuda()), ops.quantize_mxfp8(w.cuda())
-        aq, wq = ref_fp8.mx_fake_quant(a).double(), ref_fp8.mx_fake_quant(w).double()
-        S = aq @ wq.t(); T = aq.abs() @ wq.abs().t()
-        out = torch.empty(M, N, dtype=BF, device="cuda"); ops.gemm(a8, w8, out, ops.EPI_BIAS); torch.cuda.synchronize()
-        got = out.double().cpu()
-        err = (got - S).abs()
-        excess = (err - S.abs() * 2.0 ** -8).clamp_min(0)     # beyond a full bf16 ulp of the exact sum
-        rel = (excess / T)
-        # the same sum in float32 sequential order
-        S32 = (aq.float() @ wq.float().t()).double()
-        print(f"K={K} std {astd}/{wstd}: max excess error / sum|a||w| = {rel.max().item():.3e} (2^{np.log2(max(rel.max().item(),1e-30)):.1f}); "
-              f"fraction of outputs with excess > 2^-16 T: {(rel > 2.0**-16).float().mean().item():.4f}; "
-              f"torch fp32 matmul vs exact: {((S32 - S).abs() / T).max().item():.2e}")
-# per-product truncation? one big product + many tiny ones
-M = N = 256; K = 128
-a = torch.zeros(M, K); w = torch.zeros(N, K)
-a[:, 0] = 1.0; w[:, 0] = 1.0           # product 1.0 in block 0
-a[:, 32:64] = 2.0 ** -6; w[:, 32:64] = 2.0 ** -6   # 32 products of 2^-12 in block 1 (own scales)
-a[:, 64:96] = 2.0 ** -10; w[:, 64:96] = 2.0 ** -10   # 32 products of 2^-20
-a = a.to(BF); w = w.to(BF)
-a8, w8 = ops.quantize_mxfp8(a.cuda()), ops.quantize_mxfp8(w.cuda())
-out = torch.empty(M, N, dtype=torch.float32, device="cuda")
-# read the fp32-ish value through a bf16 output is too coarse: use residual trick: res = -1 (bf16 exact) -> out = bf16(acc) + res
-o16 = torch.empty(M, N, dtype=BF, device="cuda")
-res = torch.full((M, N), -1.0, dtype=BF, device="cuda")
-ops.gemm(a8, w8, o16, ops.EPI_BIAS, bias=torch.full((N,), -1.0, dtype=BF, device="cuda"))
-print("1 + 32*2^-12 + 32*2^-20 - 1 =", 32 * 2.0 ** -12 + 32 * 2.0 ** -20, " got", o16[0, 0].item(), o16[5, 7].item())
+from test_kernels_gpu import rnd
+from util import bf16_ulps
+BF = torch.bfloat16; cuda = torch.device("cuda")
+M, K = 2200, 2048
+x = rnd(M, K, std=1.5, seed=1); gain = (rnd(K, std=0.2, seed=2).float() + 1.0).to(BF); xc = x.to(cuda)
+rstd = torch.empty(ops.padded_rows(M), dtype=torch.float32, device=cuda); ops.row_stats(xc, rstd, None, 1e-5)
+xd = x.double(); r = 1.0 / torch.sqrt((xd * xd).mean(1, keepdim=True) + 1e-5)
+ff = 256
+w1, w3 = rnd(ff, K, std=0.1, seed=6), rnd(ff, K, std=0.1, seed=7)
+w13 = torch.stack([w1.view(ff // 16, 16, K), w3.view(ff // 16, 16, K)], dim=1).reshape(2 * ff, K)
+w13f = (w13.float() * gain.float()[None, :]).to(BF)
+w1f, w3f = (w1.float() * gain.float()[None, :]).to(BF), (w3.float() * gain.float()[None, :]).to(BF)
+gx = (r * (xd @ w1f.double().t())); ux = (r * (xd @ w3f.double().t()))
+g = gx.float().to(BF); u = ux.float().to(BF)
+ref = (F.silu(g.float()).to(BF).float() * u.float()).to(BF)
+for tile in (64, 128, 256):
+    out = torch.empty(M, ff, dtype=BF, device=cuda)
+    ops.gemm(xc, w13f.to(cuda), out, ops.EPI_SILU_MUL, folded_norm=(rstd,), tile=tile)
+    ul = bf16_ulps(out.float().cpu(), ref.float())
+    bad = (ul > 3) & ((out.float().cpu() - ref.float()).abs() > 2e-3)
+    print("tile", tile, "bad", int(bad.sum()))
+    for (i, j) in bad.nonzero().tolist()[:5]:
+        print("  at", i, j, "g exact", gx[i, j].item(), "g bf16", g[i, j].item(), "u", ux[i, j].item(), "out", out[i, j].item(), "ref", ref[i, j].item(),
+              "silu(g) bf16", F.silu(g[i, j].float()).to(BF).item())
