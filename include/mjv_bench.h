@@ -15,6 +15,7 @@ extern "C" {
 /* GEMM: 0 resets everything.  4000 / 4001 split-K of 128-tile launches off / on; 4200 / 4201 K-sliced 256-tile launches off / on;
  * 4100 + s caps the slices per tile at s (1..8); 4300 + n sets the fewest K-tiles per 256-tile slice; 2000 + g forces the
  * group-M of the tile order (2000 = per shape); 6000 + m = largest M the skinny kernel takes (6000 = never);
+ * 7000 / 7001 / 7002 streaming (nt) output stores by shape / never / always;
  * 1000 / 1003 / 1004 / 1006 select the 256-tile kernel's variants (1003: no epilogue, 1004: no global stores - wrong results;
  * 1006: s_memtime stamps of wave 0 to the stamp buffer; 1008: the persistent kernel with shader-clock / 100 MHz stamps around
  * every tile's main loop, summed per workgroup into slots 2 / 6 of its 8 x uint64 and the tile count into slot 7 - zero the

@@ -89,6 +89,15 @@ MJV_DEV unsigned pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
+// 16-byte output store, streaming (nt) on request.  The nt form is inline assembly: written as `if (nt)
+// __builtin_nontemporal_store(...) else plain store`, hipcc (ROCm 7.2) merges the two arms into ONE plain store and the hint is
+// gone (the kernels of rounds 1-3 contained no nt store at all - found in round 4 by reading the ISA).  Counted in vmcnt like
+// any store; nothing ever waits for it.
+MJV_DEV void store16(u16* dst, const u32x4& val, int nt) {
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(val) : "memory");
+  else *(u32x4*)dst = val;
+}
+
 MJV_DEV long out_row_of(const GemmArgs& p, int m) {
   if (p.out_rows) return p.out_rows[m];
   if (p.out_group > 0) {
@@ -1035,8 +1044,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         // streaming (nt) stores for the short-K GEMMs with large outputs: their store bursts otherwise evict the
         // operand panels the XCD's CUs share from its 4 MiB L2 (measured +5-7 % on the ViT K = 1024 GEMMs, neutral
         // to slightly negative on the LLM shapes, which therefore keep plain stores)
-        if (p.nt_store) __builtin_nontemporal_store(val, (u32x4*)dst);
-        else *(u32x4*)dst = val;
+        store16(dst, val, p.nt_store);
       }
     }
   }
@@ -1440,8 +1448,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
           val = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
         }
         u16* dst = p.C + (plain ? (long)(p.m_base + m0 + ml) : out_row_of(p, p.m_base + m0 + ml)) * p.ldc + n;
-        if (p.nt_store) __builtin_nontemporal_store(val, (u32x4*)dst);
-        else *(u32x4*)dst = val;
+        store16(dst, val, p.nt_store);
       }
       __syncthreads();   // the window is rewritten by the next half / refilled by the next tile's K-tile 1
     }
@@ -1465,6 +1472,7 @@ struct GemmTune {
   int variant = 0;          // 256-tile kernel variant (3: no epilogue, 4: no global stores, 6: s_memtime stamps)
   int split256_min_kt = 8;  // fewest K-tiles per slice of the K-sliced 256-tile launches
   int split256 = 1;         // under-filled problems with deep K run as K slices of 256 x 256 tiles
+  int nt = -1;              // streaming output stores: -1 = by shape, 0 / 1 = never / always
   void* stamp_buffer = nullptr;
 };
 #ifdef MJV_BENCH
@@ -1500,7 +1508,9 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
 #endif
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<MJV_EPI_BIAS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
-    if constexpr (EPI != MJV_EPI_ROPE_QKV)
+    // (the persistent form is instantiated for the three epilogues that launch it - ADVICE r3: the LayerScale / GELU
+    // instantiations were compiled, spilled 13 / 62 registers and were never launched or tested)
+    if constexpr (EPI == MJV_EPI_BIAS || EPI == MJV_EPI_BIAS_RELU || EPI == MJV_EPI_SILU_MUL)
       (void)hipFuncSetAttribute((const void*)t256::gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     // a norm folded into the GEMM: LayerNorm into the ViT's qkv / fc1 (bias epilogues), RMSNorm into wqkv / w1|w3
     if constexpr (EPI == MJV_EPI_BIAS || EPI == MJV_EPI_BIAS_GELU)
@@ -1570,7 +1580,7 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
       if (MJV_TUNE(variant) == 9) persistent = false;   // A/B: the one-tile-per-workgroup kernel
       a.ws = MJV_TUNE(variant) == 8 ? (float*)MJV_TUNE(stamp_buffer) : nullptr;   // 1008: main-loop clock stamps (persistent form)
 #endif
-      if constexpr (EPI != MJV_EPI_ROPE_QKV) {
+      if constexpr (EPI == MJV_EPI_BIAS || EPI == MJV_EPI_BIAS_RELU || EPI == MJV_EPI_SILU_MUL) {
         if (persistent) {
           hipLaunchKernelGGL((t256::gemm256p_kernel<EPI>), dim3(g_num_cus), dim3(512), t256::LDS_BYTES, s, a);
           return mjv_check_launch("gemm_bf16");
@@ -1613,6 +1623,7 @@ extern "C" int mjv_bench_gemm_set(int32_t code) {
   if (code == 4000 || code == 4001) { g_tune.split_k = code - 4000; return MJV_OK; }
   if (code >= 2000 && code < 2100) { g_tune.gm = code - 2000; return MJV_OK; }               // 2000: back to the per-shape choice
   if (code >= 1000 && code < 1010) { g_tune.variant = code - 1000; return MJV_OK; }           // 1000: production kernel
+  if (code >= 7000 && code <= 7002) { g_tune.nt = code - 7001; return MJV_OK; }               // 7000: by shape, 7001: never, 7002: always
   if (code == 0) { g_tune = GemmTune{}; return MJV_OK; }
   mjv_set_error("bench_gemm_set: unknown code %d", code);
   return MJV_E_ARG;
@@ -1674,7 +1685,12 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   } else {
     MJV_REQUIRE(!d->row_shift && !d->col_shift && !d->bias_f32, "gemm: row_shift / col_shift / bias_f32 need row_scale");
   }
-  a.nt_store = (d->K <= 1024 && (double)d->M * d->N * 2.0 >= 64.0 * 1024 * 1024) ? 1 : 0;
+  // streaming stores for every large output (round 4, once the stores really were nt - see store16: qkv +8 %, proj +4 %,
+  // fc1 +3 %, every other model shape +0.3 ... +0.8 % in tools/gemm_bench.py 7001 7002; in the model, one box, two rounds:
+  // never 93.5 ms per step, K <= 1024 only 92.6, always 92.3 - profiles/r04_g_nt_stores.txt); small outputs, which the next
+  // kernel reads back from the L2, keep plain stores
+  a.nt_store = ((double)d->M * (d->epilogue == MJV_EPI_SILU_MUL ? d->N / 2 : d->N) * 2.0 >= 32.0 * 1024 * 1024) ? 1 : 0;
+  if (MJV_TUNE(nt) >= 0) a.nt_store = MJV_TUNE(nt);
   const bool big = force_tile ? force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;
   g_num_cus = mjv_device_cus();   // tail peeling and split-K plan against the CUs of THIS device (partitioned parts differ)

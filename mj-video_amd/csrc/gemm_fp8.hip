@@ -124,6 +124,17 @@ MJV_DEV void stage_half(const StagePtrs& sp, int t, int nk, char* smem, int wave
                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
 }
 
+// streaming (nt) stores as inline assembly: `if (nt) __builtin_nontemporal_store(..) else plain` is merged into one PLAIN
+// store by hipcc (ROCm 7.2) - see gemm.hip store16
+MJV_DEV void store16(u16* dst, const u32x4& val, int nt) {
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(val) : "memory");
+  else *(u32x4*)dst = val;
+}
+MJV_DEV void store8(uint8_t* dst, const u32x2& val, int nt) {
+  if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst), "v"(val) : "memory");
+  else *(u32x2*)dst = val;
+}
+
 #define MJV_BARRIER()                      \
   do {                                     \
     __builtin_amdgcn_sched_barrier(0);     \
@@ -406,8 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
       unsigned sb;
       const u32x2 q = mx8_quantize_quad(vals[it], sb);
       if (m0 + ml >= p.M || n >= nlim) continue;
-      if (p.nt_store) __builtin_nontemporal_store(q, (u32x2*)(crow + it * cstep));
-      else *(u32x2*)(crow + it * cstep) = q;
+      store8(crow + it * cstep, q, p.nt_store);
       if ((tid & 3) == 0) p.Cs[mx8_scale_offset(m0 + ml, n, p.c_groups)] = (uint8_t)sb;
     }
   } else {
@@ -430,8 +440,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
         for (int e = 0; e < 8; ++e) v[e] += rs[e];
         val = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
       }
-      if (p.nt_store) __builtin_nontemporal_store(val, (u32x4*)(crow + it * cstep));
-      else *(u32x4*)(crow + it * cstep) = val;
+      store16(crow + it * cstep, val, p.nt_store);
     }
   }
 }
@@ -483,7 +492,7 @@ int mjv_gemm_mxfp8_dispatch(const mjv_gemm_desc* d, void* stream) {
   a.bias = d->bias; a.scale = d->scale; a.res = d->res; a.ldr = d->ldr;
   a.tiles_m = a.tiles_n = 0;
   a.gm = d->K <= 2048 ? 5 : (d->K >= 16384 || d->N >= 8192) ? 4 : 8;   // (gemm.hip pick_gm by K BYTES per row)
-  a.nt_store = (d->K <= 2048 && (double)d->M * nout * (out8 ? 1.0 : 2.0) >= 64.0 * 1024 * 1024) ? 1 : 0;
+  a.nt_store = ((double)d->M * nout * (out8 ? 1.0 : 2.0) >= 32.0 * 1024 * 1024) ? 1 : 0;   // (gemm.hip: streaming stores for large outputs)
   hipStream_t s = (hipStream_t)stream;
   static const char* const tags[] = {"gemm256f8_bias", "gemm256f8_bias_gelu", "gemm256f8_bias_relu", "gemm256f8_scale_res", "gemm256f8_silu_mul"};
   const double flops = 2.0 * d->M * (double)d->N * d->K;

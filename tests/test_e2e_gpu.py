@@ -96,6 +96,19 @@ def bits_to_f32(a):
 # layer by layer, and two samples of that noise differ by sqrt(2) x one: 3 % for the vision tower (24 layers, LayerScale-
 # damped residual updates), 4 % for the language tower's deepest layers.
 LAYER_TOL = {"vit": 0.03, "llm": 0.04}
+# Per layer (round 4): tests/golden/layers.npz holds the reference's OWN one-layer noise at production shape -
+# its bf16 run against its fp32 run: 0.30 % per vision layer, 0.44 % per language layer - and the whole-row probes of the full
+# fixtures show it compounding like a random walk (HIP vs reference, measured: vision 0.19 / 0.70 / 0.98 / 1.18 / 1.36 % at layers
+# 0 / 5 / 11 / 17 / 23 = 0.30 % x sqrt(L + 1) within 10 %; language 0.65 / 1.65 / 2.3 / 2.8 % at 0 / 7 / 15 / 23, which enters
+# with the 0.48 % the image rows bring along).  Bound = 2 x that model (two samples of one noise differ by sqrt(2) x one, and
+# attention mixing runs the language tower ~20 % above the pure random walk), never above the flat figure.
+ONE_LAYER_NOISE = {"vit": 0.0030, "llm": 0.0044}
+LLM_ENTRY_NOISE = 0.0048
+
+
+def layer_tol(tower, L):
+    base = LLM_ENTRY_NOISE if tower == "llm" else 0.0
+    return min(2.0 * float(np.sqrt(ONE_LAYER_NOISE[tower] ** 2 * (L + 1) + base ** 2)), LAYER_TOL[tower])
 
 
 def rel_l2(a, b):
@@ -198,13 +211,13 @@ def _full_case(cuda, tag, image_size):
                     got = probes[f"vit_layer{L}"][i * tiles, :rp["vit_rows"], :].float().cpu().numpy()
                     e = rel_l2(got, ref)
                     layer_report.append((tag, p, f"vit{L}", round(e, 4)))
-                    assert e < LAYER_TOL["vit"], (tag, p, "vit_layer", L, e)
+                    assert e < layer_tol("vit", L), (tag, p, "vit_layer", L, e, layer_tol("vit", L))
                 for L in rp["llm_layers"]:
                     ref = bits_to_f32(npz[f"{p}/probe/llm_layer{L}_rows"])
                     got = probes[f"llm_layer{L}"][hi_row - rp["llm_rows"]:hi_row, :].float().cpu().numpy()
                     e = rel_l2(got, ref)
                     layer_report.append((tag, p, f"llm{L}", round(e, 4)))
-                    assert e < LAYER_TOL["llm"], (tag, p, "llm_layer", L, e)
+                    assert e < layer_tol("llm", L), (tag, p, "llm_layer", L, e, layer_tol("llm", L))
         for f in FIELDS:
             got = getattr(out, f)[i].float().cpu().numpy()
             ref = npz[f"{p}/{f}"][0]

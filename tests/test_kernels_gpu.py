@@ -564,16 +564,36 @@ def test_gemm_pipeline_race_screen(cuda):
     from mj_video_amd import ops
     ops.gemm_set_tile(256)
     try:
-        M, N, K = 4096 + 37, 2048, 1024
-        g = torch.Generator().manual_seed(11)
-        a = torch.randint(-3, 4, (M, K), generator=g).float().to(BF).to(cuda)
-        w = torch.randint(-3, 4, (N, K), generator=g).float().to(BF).to(cuda)
-        ref = (a.float() @ w.float().t()).to(BF)
-        out = torch.empty(M, N, dtype=BF, device=cuda)
+        # 136 tiles: the one-tile-per-workgroup kernel; 396 tiles (> 256 CUs, 16 K-tiles): the PERSISTENT kernel, whose first
+        # wait per tile is a counted vmcnt that leaves the previous tile's stores in flight (its only guard was a
+        # bit-equality test at two shapes)
+        for M, N, K in ((4096 + 37, 2048, 1024), (8192 + 37, 3072, 1024), (8192, 3072, 256)):
+            g = torch.Generator().manual_seed(11)
+            a = torch.randint(-3, 4, (M, K), generator=g).float().to(BF).to(cuda)
+            w = torch.randint(-3, 4, (N, K), generator=g).float().to(BF).to(cuda)
+            ref = (a.float() @ w.float().t()).to(BF)
+            out = torch.empty(M, N, dtype=BF, device=cuda)
+            for it in range(20):
+                out.zero_()
+                ops.gemm(a, w, out, ops.EPI_BIAS)
+                assert torch.equal(out, ref), f"{M}x{N}x{K} iteration {it}: {(out != ref).sum().item()} wrong elements"
+        # the persistent SiLU-mul form (8 stores per tile behind the prefetch instead of 16)
+        M, ff, K = 8192 + 64, 2048, 512
+        g = torch.Generator().manual_seed(12)
+        a = torch.randint(-2, 3, (M, K), generator=g).float().to(BF).to(cuda)
+        w1 = torch.randint(-2, 3, (ff, K), generator=g).float().to(BF)
+        w3 = torch.randint(-2, 3, (ff, K), generator=g).float().to(BF)
+        w13 = torch.stack([w1.view(ff // 16, 16, K), w3.view(ff // 16, 16, K)], dim=1).reshape(2 * ff, K).contiguous().to(cuda)
+        gg, uu = (a.float().cpu() @ w1.float().t()).to(BF), (a.float().cpu() @ w3.float().t()).to(BF)
+        ref = (F.silu(gg) * uu)
+        first = torch.empty(M, ff, dtype=BF, device=cuda)
+        ops.gemm(a, w13, first, ops.EPI_SILU_MUL)
+        assert_close_bf16(first, ref, 3, frac_exact=0.95, atol=2e-3, what="persistent silu")
+        out = torch.empty_like(first)
         for it in range(20):
             out.zero_()
-            ops.gemm(a, w, out, ops.EPI_BIAS)
-            assert torch.equal(out, ref), f"iteration {it}: {(out != ref).sum().item()} wrong elements"
+            ops.gemm(a, w13, out, ops.EPI_SILU_MUL)
+            assert torch.equal(out, first), f"persistent silu iteration {it}"
     finally:
         ops.gemm_set_tile(0)
 

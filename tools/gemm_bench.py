@@ -32,6 +32,9 @@ def bench(M, N, K, epi, tile, iters=20):
         ops.set_gemm_workspace(WS)
         ops.gemm_set_tile(4300 + tile - 9000)
         ops.gemm_set_tile(0)
+    elif tile in (7001, 7002):   # streaming (nt) output stores never / always, automatic tile choice
+        ops.gemm_set_tile(tile)
+        ops.gemm_set_tile(0)
     elif tile >= 5000:      # 5000 + tile: same tile choice with a split-K workspace
         WS = WS if WS is not None else torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
         ops.set_gemm_workspace(WS)
@@ -50,7 +53,7 @@ def bench(M, N, K, epi, tile, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    ops.gemm_set_tile(2000); ops.gemm_set_tile(4201); ops.gemm_set_tile(4308); ops.gemm_set_tile(0); ops.set_gemm_workspace(None)
+    ops.gemm_set_tile(2000); ops.gemm_set_tile(4201); ops.gemm_set_tile(4308); ops.gemm_set_tile(7000); ops.gemm_set_tile(0); ops.set_gemm_workspace(None)
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
