@@ -129,6 +129,11 @@ def load_library():
         if _lib is not None:
             return _lib
         path = os.environ.get("MJV_LIBRARY") or LIB_PATH   # (tools: the bench / stamp builds of the same sources)
+        if path != LIB_PATH:
+            import warnings
+            warnings.warn(f"MJV_LIBRARY={path}: NOT the product library ({LIB_PATH}) - the bench / stamp builds carry process-wide "
+                          "measurement switches and kernel variants that are wrong by construction; scoring entry points refuse "
+                          "them (assert_product_library)", RuntimeWarning, stacklevel=2)
         if not os.path.isfile(path):
             raise MjvLibraryError(
                 f"{path} not found: the HIP extension is required (python -c 'import __graft_entry__ as g; "
@@ -151,6 +156,19 @@ def load_library():
             raise MjvLibraryError(f"ABI version mismatch: library {lib.mjv_abi_version()} != binding {ABI_VERSION}")
         _lib = lib
         return lib
+
+
+def is_bench_build() -> bool:
+    """True when the loaded library exports the measurement switches of include/mjv_bench.h (libmjv_hip_bench.so)"""
+    return getattr(getattr(load_library(), "mjv_bench_gemm_set", None), "argtypes", None) is not None
+
+
+def assert_product_library() -> None:
+    """Scoring entry points (scripts/eval/*, the harness) call this: an inherited MJV_LIBRARY must not silently swap the bench
+    build - process-wide switches, variants that skip work - under an evaluation."""
+    if is_bench_build():
+        raise MjvLibraryError("the bench build of the library (libmjv_hip_bench.so, MJV_LIBRARY) is loaded: it carries process-wide "
+                              "measurement switches and must not score; unset MJV_LIBRARY")
 
 
 def check(rc: int, what: str) -> None:

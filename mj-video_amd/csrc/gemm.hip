@@ -843,6 +843,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
       for (int it = 0; it < PASSES; ++it) {
         rsv[it] = u32x4{0u, 0u, 0u, 0u};
+        // (nt LOADS for these once-read rows were measured in round 4 - inline asm + a hand-placed wait: proj +2.7 %, fc2 -0.7 %,
+        // wo -5 %, w2 +0.7 %: not kept)
         if (m0 + it * ROWS_PER_PASS + ml0 < p.M && n < nlim) rsv[it] = *(const u32x4*)(rp + it * rstep);
       }
     }
@@ -1020,6 +1022,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     u32x4 vals[PASSES];
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) vals[it] = *(const u32x4*)(etile + (it * ROWS_PER_PASS + ml0) * EPI_PITCH + c8 * 2);
+
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
       const int ml = it * ROWS_PER_PASS + ml0;

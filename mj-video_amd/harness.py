@@ -76,6 +76,54 @@ def pad_right(ids_list: Sequence[torch.Tensor], pad_id: int):
     return ids, mask
 
 
+def prefetch_to_device(batches: Iterable, device, depth: int = 1):
+    """Yields the items of ``batches`` (tensors, or tuples / lists / dicts of tensors; anything else passes through) moved to
+    ``device``, with the upload of the NEXT ``depth`` items already running on a copy stream of its own: batch i + 1 crosses
+    PCIe while batch i is scored, so a caller that starts from host memory sees the HBM-resident rate (without this the copies
+    sit on the scoring stream: -1.8 % with bf16 pixel tensors, -4.5 % with uint8 720p frames, profiles/r03_f_pcie_inclusive.txt).
+    Host tensors are pinned here if they are not yet (an unpinned source makes the copy synchronous).  The yielded tensors are
+    safe to use on the current stream (it waits for the copy's event; ``record_stream`` keeps the allocator from recycling
+    them under the scoring kernels)."""
+    from collections import deque
+    device = torch.device(device)
+    side = torch.cuda.Stream(device=device)
+
+    def move(x, fn):
+        if isinstance(x, torch.Tensor):
+            return fn(x)
+        if isinstance(x, dict):
+            return {k: move(v, fn) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return type(x)(move(v, fn) for v in x)
+        return x
+
+    def start(item):
+        def up(t):
+            if t.is_cuda:
+                return t
+            return (t if t.is_pinned() else t.pin_memory()).to(device, non_blocking=True)
+        with torch.cuda.stream(side):
+            dev_item = move(item, up)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return dev_item, ev
+
+    def finish(entry):
+        dev_item, ev = entry
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(ev)
+        move(dev_item, lambda t: (t.record_stream(cur), t)[1] if t.is_cuda else t)
+        return dev_item
+
+    pending = deque()
+    for item in batches:
+        pending.append(start(item))
+        if len(pending) > depth:
+            yield finish(pending.popleft())
+    while pending:
+        yield finish(pending.popleft())
+
+
 @torch.no_grad()
 def score_pair_batch(model, config, tokenizer, examples: Sequence[dict], generation_config: dict) -> torch.Tensor:
     """examples: dicts with ``prompt``, ``left_pixels``, ``right_pixels`` (each [F,3,S,S] bf16).  Both videos of

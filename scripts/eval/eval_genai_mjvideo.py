@@ -67,26 +67,51 @@ def build_model(args, tokenizer, device):
     return config, model
 
 
-def load_pixels(path, args, device):
+def load_host(path, args):
+    """what a video is in HOST memory before it crosses PCIe: preprocessed bf16 pixel tiles (--host-preprocessing, the
+    reference's load_video) or the decoded uint8 frames (default: resize / normalise run on the GPU)"""
     if args.host_preprocessing:
         pv, _ = video.load_video(path, num_segments=args.num_segments, max_num=args.max_num)
         return pv.to(torch.bfloat16)
-    frames = video.decode_frames(path, num_segments=args.num_segments)
-    pv, _ = video.load_frames_device(torch.from_numpy(frames).to(device), max_num=args.max_num)
+    return torch.from_numpy(video.decode_frames(path, num_segments=args.num_segments))
+
+
+def to_pixels(t, args):
+    """device tensor of load_host -> [tiles, 3, S, S] bf16 pixel tiles"""
+    if t.dtype == torch.bfloat16:
+        return t
+    pv, _ = video.load_frames_device(t, max_num=args.max_num)
     return pv
 
 
-def evaluate_examples(model, config, tokenizer, examples, pixel_loader, pairs_per_batch=4, generation_config=None):
+def load_pixels(path, args, device):
+    return to_pixels(load_host(path, args).to(device), args)
+
+
+def evaluate_examples(model, config, tokenizer, examples, pixel_loader, pairs_per_batch=4, generation_config=None,
+                      host_loader=None, to_device_pixels=None):
     """Scores ``examples`` (dicts with prompt / left_video / right_video / vote_type), data-parallel when a process group
-    exists, and returns (PreferenceCounts, scores [n, 2, W]) - identical on every rank."""
+    exists, and returns (PreferenceCounts, scores [n, 2, W]) - identical on every rank.  With ``host_loader`` (path -> host
+    tensor) and ``to_device_pixels`` (device tensor -> pixel tiles) the videos of batch i + 1 are decoded and uploaded on a
+    copy stream while batch i is scored (harness.prefetch_to_device); ``pixel_loader`` alone is the serial form."""
     generation_config = generation_config if generation_config is not None else {"max_new_tokens": 1024, "do_sample": True}
 
     def score_fn(local):
         blocks = []
-        for i in range(0, len(local), pairs_per_batch):
-            chunk = [dict(prompt=ex["prompt"], left_pixels=pixel_loader(ex["left_video"]),
-                          right_pixels=pixel_loader(ex["right_video"])) for ex in local[i:i + pairs_per_batch]]
-            blocks.append(harness.score_pair_batch(model, config, tokenizer, chunk, generation_config).float())
+        starts = range(0, len(local), pairs_per_batch)
+        if host_loader is not None:
+            host_chunks = ([(host_loader(ex["left_video"]), host_loader(ex["right_video"])) for ex in local[i:i + pairs_per_batch]]
+                           for i in starts)
+            dev_chunks = harness.prefetch_to_device(host_chunks, model.model.device)
+            for i, dev in zip(starts, dev_chunks):
+                chunk = [dict(prompt=ex["prompt"], left_pixels=to_device_pixels(l), right_pixels=to_device_pixels(r))
+                         for ex, (l, r) in zip(local[i:i + pairs_per_batch], dev)]
+                blocks.append(harness.score_pair_batch(model, config, tokenizer, chunk, generation_config).float())
+        else:
+            for i in starts:
+                chunk = [dict(prompt=ex["prompt"], left_pixels=pixel_loader(ex["left_video"]),
+                              right_pixels=pixel_loader(ex["right_video"])) for ex in local[i:i + pairs_per_batch]]
+                blocks.append(harness.score_pair_batch(model, config, tokenizer, chunk, generation_config).float())
         return torch.cat(blocks) if blocks else torch.zeros(0, 2, parallel.SCORE_WIDTH, device=model.model.device)
 
     scores = parallel.score_pairs_dp(score_fn, list(examples), device=model.model.device)
@@ -97,6 +122,8 @@ def evaluate_examples(model, config, tokenizer, examples, pixel_loader, pairs_pe
 
 def main(argv=None):
     args = parse_args(argv)
+    from mj_video_amd import _lib
+    _lib.assert_product_library()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
@@ -109,7 +136,8 @@ def main(argv=None):
     config, model = build_model(args, tokenizer, device)
     text = open(args.examples).read().strip()
     examples = json.loads(text) if text.startswith("[") else [json.loads(l) for l in text.splitlines() if l.strip()]
-    counts, _ = evaluate_examples(model, config, tokenizer, examples, lambda p: load_pixels(p, args, device), args.pairs_per_batch)
+    counts, _ = evaluate_examples(model, config, tokenizer, examples, lambda p: load_pixels(p, args, device), args.pairs_per_batch,
+                                  host_loader=lambda p: load_host(p, args), to_device_pixels=lambda t: to_pixels(t, args))
     if not dist.is_initialized() or dist.get_rank() == 0:
         print(f"prefer_Acc: {counts.prefer_acc}")
         print(f"Acc: {counts.acc}")

@@ -71,6 +71,8 @@ def evaluate_items(model, config, tokenizer, items, pixel_loader, root, pairs_pe
 
 def main(argv=None):
     args = parse_args(argv)
+    from mj_video_amd import _lib
+    _lib.assert_product_library()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)

@@ -843,6 +843,31 @@ def test_eval_driver_protocol(cuda):
     assert (counts.prefer_truth, counts.prefer_total, counts.truth, counts.total) == \
         (ref.prefer_truth, ref.prefer_total, ref.truth, ref.total)
     assert counts.total == 5 and counts.prefer_total == 3
+    # the prefetching form (decoded frames in host memory, uploads of batch i + 1 on a copy stream while batch i is scored):
+    # bit-identical scores, same counts
+    counts2, scores2 = drv.evaluate_examples(model, cfg, tok, examples, None, pairs_per_batch=2,
+                                             host_loader=lambda name: torch.from_numpy(store[name]),
+                                             to_device_pixels=lambda t: video.load_frames_device(t, input_size=56, max_num=1)[0])
+    assert torch.equal(scores2, scores)
+    assert (counts2.prefer_truth, counts2.truth, counts2.total) == (counts.prefer_truth, counts.truth, counts.total)
+
+
+def test_prefetch_to_device_order_values_and_nesting(cuda):
+    """harness.prefetch_to_device: every item arrives, in order, bit for bit, whatever the nesting (tensor / tuple / dict),
+    usable on the current stream straight away, with one or two uploads in flight"""
+    from mj_video_amd import harness
+    g = torch.Generator().manual_seed(1)
+    items = [dict(a=torch.randn(3, 1000, generator=g), b=(torch.randint(0, 255, (2, 777), dtype=torch.uint8, generator=g), i))
+             for i in range(7)]
+    for depth in (1, 2):
+        got = []
+        for it in harness.prefetch_to_device(iter(items), cuda, depth=depth):
+            assert it["a"].is_cuda and it["b"][0].is_cuda
+            got.append((it["a"] * 2.0, it["b"][0].clone(), it["b"][1]))      # consume on the current stream immediately
+        torch.cuda.synchronize()
+        assert len(got) == 7
+        for i, (a2, b, tag) in enumerate(got):
+            assert tag == i and torch.equal(a2.cpu(), items[i]["a"] * 2.0) and torch.equal(b.cpu(), items[i]["b"][0])
 
 
 def test_mjbench_video_driver(cuda):

@@ -490,3 +490,42 @@ def test_load_video_end_to_end_with_a_stub_decoder(monkeypatch):
     assert all(p == "/videos/clip.mp4" and n == 1 for p, _, n in opened)
     with pytest.raises(RuntimeError, match="no network"):
         video.load_video("https://example.com/clip.mp4")
+
+
+def test_persistent_gemm_counted_wait_matches_the_emitted_stores():
+    """gemm256p_kernel waits for the prefetched K-tile with s_waitcnt vmcnt(N), N = the previous tile's pass-B stores + the 4
+    LDS-DMA instructions issued behind the prefetch: a wait for the DMA that does not also drain the stores.  N is spelled out
+    in the source (20 / 12), so it has to be checked against what the compiler actually emitted: per persistent
+    instantiation, the number of 16-byte store instructions per tile - each store site is a plain arm and an inline-asm nt arm,
+    exactly one of which executes - must be N - 4."""
+    import re
+    import subprocess
+    import tempfile
+    from mj_video_amd import _lib
+    src = os.path.join(_lib.CSRC_DIR, "gemm.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "gemm.s")
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}",
+                            f"-I{_lib.CSRC_DIR}", "-S", "--cuda-device-only", src, "-o", out], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        text = open(out).read()
+    kernels = re.findall(r"^(_ZN\S*gemm256p_kernel\S*):.*?\.end_amdhsa_kernel", text, re.S | re.M)
+    bodies = {m.group(1): m.group(0) for m in re.finditer(r"^(_ZN\S*gemm256p_kernel\S*):.*?\.end_amdhsa_kernel", text, re.S | re.M)}
+    assert len(bodies) >= 3 and len(kernels) == len(bodies)
+    for name, body in bodies.items():
+        plain = len(re.findall(r"global_store_dwordx4 [^\n]*off\s*$", body, re.M))
+        nt = len(re.findall(r"global_store_dwordx4 [^\n]*off nt\s*$", body, re.M))
+        waits = sorted({int(w) for w in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)})
+        assert plain == nt and plain in (8, 16), (name, plain, nt)
+        assert waits == [0, 4, plain + 4], (name, plain, waits)
+
+
+def test_scoring_entry_points_refuse_the_bench_library(monkeypatch):
+    from mj_video_amd import _lib
+    _lib.load_library()
+    assert not _lib.is_bench_build()
+    _lib.assert_product_library()
+    monkeypatch.setattr(_lib, "is_bench_build", lambda: True)
+    with pytest.raises(_lib.MjvLibraryError, match="bench build"):
+        _lib.assert_product_library()

@@ -53,8 +53,28 @@ def from_host_frames():
     model.forward(pv, ids.to(dev), mask.to(dev))
 
 
+def prefetched(host_batch, to_px, steps=8):
+    """the same step fed through harness.prefetch_to_device: batch i + 1 uploads on a copy stream while batch i is scored"""
+    from mj_video_amd import harness
+
+    def run(n):
+        for t in harness.prefetch_to_device((host_batch for _ in range(n)), dev):
+            model.forward(to_px(t), ids.to(dev), mask.to(dev))
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 for name, fn, mb in (("pixels resident in HBM", resident, 0.0),
                      ("bf16 pixel tensors from pinned host memory", from_host_pixels, px_host.numel() * 2 / 1e6),
                      ("uint8 720p frames from pinned host memory + device preprocessing", from_host_frames, frames_host.numel() / 1e6)):
     ms = timed(fn)
     print(f"{name:70s} {ms:8.2f} ms per 4-pair step = {4e3 / ms:6.2f} pairs/s   ({mb:6.1f} MB over PCIe per step)")
+for name, host, to_px, mb in (("bf16 pixel tensors from pinned host memory, uploads prefetched on a copy stream", px_host, lambda t: t, px_host.numel() * 2 / 1e6),
+                             ("uint8 720p frames from pinned host memory, uploads prefetched + device preprocessing", frames_host,
+                              lambda t: video.load_frames_device(t, input_size=S, max_num=1)[0], frames_host.numel() / 1e6)):
+    ms = prefetched(host, to_px)
+    print(f"{name:90s} {ms:8.2f} ms per 4-pair step = {4e3 / ms:6.2f} pairs/s   ({mb:6.1f} MB over PCIe per step)")
