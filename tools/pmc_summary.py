@@ -18,13 +18,16 @@ EPI = ["bias", "bias_gelu", "bias_relu", "scale_res", "silu_mul", "rope_qkv"]
 
 def tag_of(k):
     """kernel name as rocprofv3 prints it -> the library's profiler tag (the key bench.py looks traffic up by)"""
-    m = re.match(r"t256::gemm256_kernel<(\d), 0>", k)
+    m = re.match(r"t256::gemm256_kernel<(\d), 0(?:, \d)?>", k)     # <EPI, VAR = 0[, FUSE]> (round 4 added the folded-norm parameter)
     if m:
         return "gemm256_" + EPI[int(m.group(1))]
-    m = re.match(r"t256::gemm256p_kernel<(\d)>", k)      # persistent form of the same tile kernel (round 3): same profiler tag
+    m = re.match(r"t256::gemm256p_kernel<(\d)(?:, \d)?>", k)      # persistent form of the same tile kernel (round 3): same profiler tag
     if m:
         return "gemm256_" + EPI[int(m.group(1))]
-    if re.match(r"t256::gemm256_kernel<0, 7>", k):
+    m = re.match(r"gemm256f8_kernel<(\d), (true|false)>", k)      # MXFP8 operands (round 4)
+    if m:
+        return "gemm256f8_" + EPI[int(m.group(1))]
+    if re.match(r"t256::gemm256_kernel<0, 7(?:, \d)?>", k):
         return "gemm256s_slices"        # K-sliced 256-tile launch: fp32 slice images to the workspace
     m = re.match(r"t256::splitk_finish256_kernel<(\d)>", k)
     if m:
@@ -38,7 +41,7 @@ def tag_of(k):
     m = re.match(r"(?:v2::attn2_kernel|attn_kernel)<(\d+), (true|false)", k)
     if m:
         return f"attn_d{m.group(1)}" + ("_causal" if m.group(2) == "true" else "")
-    for name in ("layernorm", "rmsnorm", "rope_split", "patchify", "embed_gather", "reward_heads", "cls_rows"):
+    for name in ("layernorm", "rmsnorm", "row_stats", "quantize_mxfp8", "rope_split", "patchify", "embed_gather", "reward_heads", "cls_rows"):
         if k.startswith(name):
             return name
     return None
