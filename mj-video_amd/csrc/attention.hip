@@ -1067,13 +1067,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     if (!ok) continue;
     const float inv = 1.0f / l;
     u16* op = p.O + (long)(s0 + qi[sb]) * p.ldo + (long)head * p.ohs;
+    // 16-byte stores (round 4; cdna_hip_programming.md T21): the two half-lanes of a query hold alternating 4-element chunks
+    // of its row (d = 8 g + 4 hi ..); one v_permlane32_swap per word hands the hi = 0 lane both halves of the even chunks and
+    // the hi = 1 lane both halves of the odd ones, so each stores 8 consecutive elements - half as many store instructions
+    // (both half-lanes of a query take the same branch above: the exchange is between active lanes)
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 v = {pack2bf(oacc[sb][dt][4 * g] * inv, oacc[sb][dt][4 * g + 1] * inv),
-                   pack2bf(oacc[sb][dt][4 * g + 2] * inv, oacc[sb][dt][4 * g + 3] * inv)};
-        *(u32x2*)(op + dt * 32 + 8 * g + 4 * hi) = v;
+      for (int g = 0; g < 4; g += 2) {
+        const unsigned a0 = pack2bf(oacc[sb][dt][4 * g] * inv, oacc[sb][dt][4 * g + 1] * inv);
+        const unsigned a1 = pack2bf(oacc[sb][dt][4 * g + 2] * inv, oacc[sb][dt][4 * g + 3] * inv);
+        const unsigned b0 = pack2bf(oacc[sb][dt][4 * g + 4] * inv, oacc[sb][dt][4 * g + 5] * inv);
+        const unsigned b1 = pack2bf(oacc[sb][dt][4 * g + 6] * inv, oacc[sb][dt][4 * g + 7] * inv);
+        const auto w0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);   // [0]: own (hi = 0) / partner's b; [1]: partner's a / own b
+        const auto w1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const u32x4 v = {w0[0], w1[0], w0[1], w1[1]};
+        *(u32x4*)(op + dt * 32 + 8 * (g + hi)) = v;
       }
   }
 }
