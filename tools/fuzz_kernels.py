@@ -121,9 +121,9 @@ def attn_case():
     if rng.random() < 0.1:
         lens = [rng.choice([2186, 2049, 4097, 4160])]
     N = sum(lens)
-    mode = rng.choice([0, 1])
+    mode = rng.choice([0, 1, 2])         # 2 (round 4): unrounded fp32 scores, the round-3 kernel only
     scale = D ** -0.5 if rng.random() < 0.8 else 0.1
-    kern = rng.choice([0, 0, 0, 4, 5, 6, 7])
+    kern = rng.choice([0, 0, 0, 4, 5, 6, 7]) if mode != 2 else rng.choice([0, 0, 6, 7])
     std = rng.choice([1.0, 1.0, 2.5])
     qkv = (torch.randn(N, (H + 2 * KVH) * D, device=dev) * std).to(BF)       # q / k / v as column slices (row stride != width)
     q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KVH) * D], qkv[:, (H + KVH) * D:]
@@ -139,7 +139,10 @@ def attn_case():
             kh = k[s0:s0 + L].float().view(L, KVH, D).transpose(0, 1).repeat_interleave(G, 0)
             vh = v[s0:s0 + L].float().view(L, KVH, D).transpose(0, 1).repeat_interleave(G, 0)
             sc = qh @ kh.transpose(1, 2)
-            sc = (sc.to(BF).float() * scale).to(BF).float() if mode else (sc * scale).to(BF).float()
+            if mode == 2:
+                sc = sc * scale
+            else:
+                sc = (sc.to(BF).float() * scale).to(BF).float() if mode else (sc * scale).to(BF).float()
             if causal:
                 sc = sc.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool, device=dev), 1), float("-inf"))
             p = torch.softmax(sc, -1).to(BF).float()
@@ -165,16 +168,162 @@ def attn_case():
         fails.append(tag + f": {type(e).__name__}: {e}")
 
 
-t0 = time.time()
-n_g = n_a = 0
-while time.time() - t0 < budget:
-    if rng.random() < 0.5:
-        gemm_case(); n_g += 1
+def _fq(x):
+    """MXFP8 fake-quantisation on the GPU (the arithmetic of oracle/ref_fp8.py in torch ops; the oracle itself is held to the
+    kernels bit for bit by tests/test_fp8_gpu.py): block scale = smallest power of two with amax / s <= 448, elements e4m3 RNE"""
+    shp = x.shape
+    xb = x.to(BF).reshape(-1, shp[-1] // 32, 32)
+    u = xb.view(torch.int16).to(torch.int32) & 0x7FFF
+    b = (((u.amax(dim=2) + 0x1F) >> 7) - 8).clamp_min(1)
+    xf = xb.float()
+    q = torch.ldexp(xf, (127 - b)[:, :, None].expand_as(xf)).to(torch.float8_e4m3fn).float()
+    return torch.ldexp(q, (b - 127)[:, :, None].expand_as(q)).reshape(shp)
+
+
+def gemm8_case():
+    """MXFP8 operands (round 4): random M / N / K / epilogue, bf16 or MXFP8 output; exact on small-integer data"""
+    M = rng.choice([1, 17, 64, 65, 200, 256, 257, 300, 513, 1025, 1104, rng.randrange(1, 2500), 256 * rng.randrange(1, 20) + rng.choice([0, 64, 80])])
+    K = 128 * rng.choice([1, 2, 3, 4, 5, 8, 16, 17, 32, 64])
+    epi = rng.choice(["bias", "nobias", "gelu", "relu", "scale_res", "silu"])
+    out8 = epi in ("bias", "gelu", "relu", "silu") and rng.random() < 0.5
+    N = (256 if out8 else 8) * rng.choice([1, 2, 3, 4, 8] if out8 else [1, 4, 16, 17, 32, 64, 96, 128, 129, 256, rng.randrange(1, 200)])
+    if epi == "silu" and N % 32:
+        N = (N + 31) // 32 * 32
+    if M * N > 20_000_000 or M * K > 20_000_000 or N * K > 20_000_000:
+        return
+    integer = rng.random() < 0.4 and epi in ("bias", "nobias", "relu") and not out8
+    if integer:
+        a = (torch.randint(-8, 9, (M, K), device=dev).float() * torch.exp2(torch.randint(-1, 2, (M, K // 32), device=dev).float()).repeat_interleave(32, 1)).to(BF)
+        w = (torch.randint(-7, 8, (N, K), device=dev).float() * torch.exp2(torch.randint(-1, 2, (N, K // 32), device=dev).float()).repeat_interleave(32, 1)).to(BF)
+        b = torch.randint(-8, 9, (N,), device=dev).float().to(BF)
     else:
+        a = torch.randn(M, K, device=dev).to(BF)
+        w = (torch.randn(N, K, device=dev) * 0.08).to(BF)
+        b = (torch.randn(N, device=dev) * 0.2).to(BF)
+    tag = f"gemm8 M={M} N={N} K={K} epi={epi} out8={out8} int={integer}"
+    try:
+        a8, w8 = ops.quantize_mxfp8(a), ops.quantize_mxfp8(w)
+        aq, wq = _fq(a).double(), _fq(w).double()
+        code = {"bias": ops.EPI_BIAS, "nobias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "relu": ops.EPI_BIAS_RELU,
+                "scale_res": ops.EPI_SCALE_RES, "silu": ops.EPI_SILU_MUL}[epi]
+        bias = None if epi in ("nobias", "silu") else b
+        nout = N // 2 if epi == "silu" else N
+        kw = {}
+        if epi == "scale_res":
+            res = torch.randn(M, N, device=dev).to(BF)
+            ls = (torch.randn(N, device=dev) * 0.5).to(BF)
+            kw = dict(scale=ls, res=res)
+        wk = w8
+        if epi == "silu":
+            w13 = torch.stack([w[:nout].view(nout // 16, 16, K), w[nout:].view(nout // 16, 16, K)], dim=1).reshape(N, K).contiguous()
+            wk = ops.quantize_mxfp8(w13)
+        o16 = torch.empty(M, nout, dtype=BF, device=dev)
+        ops.gemm(a8, wk, o16, code, bias=bias, **kw)
+        if out8:
+            o8 = ops.MX8.empty(M, nout, dev)
+            ops.gemm(a8, wk, o8, code, bias=bias)
+            chk = ops.quantize_mxfp8(o16)
+            torch.cuda.synchronize()
+            if not torch.equal(o8.data, chk.data):
+                fails.append(tag + f": MXFP8 output != quantise(bf16 output) ({int((o8.data != chk.data).sum())} elements)")
+            return
+        lin64 = aq @ wq.t() + (0 if bias is None else b.double())
+        T = aq.abs() @ wq.abs().t()
+        if epi == "silu":
+            g = (aq @ wq[:nout].t()).float().to(BF)
+            u = (aq @ wq[nout:].t()).float().to(BF)
+            ref = (F.silu(g) * u).float()
+            amp = 2.2 * g.float().abs() * u.float().abs() + ref.abs() + 2.0 ** -9 * (aq.abs() @ wq[:nout].abs().t() + aq.abs() @ wq[nout:].abs().t()).float() * (g.float().abs() + u.float().abs() + 1)
+        else:
+            lin = lin64.float().to(BF)
+            if epi == "scale_res":
+                t1 = lin.float()
+                ref = (res.float() + (t1 * ls.float()).to(BF).float()).to(BF).float()
+                amp = res.float().abs() + 2 * (t1 * ls.float()).abs() + 2.0 ** -9 * T.float() * (1 + ls.float().abs())
+            else:
+                ref = {"bias": lin, "nobias": lin, "gelu": F.gelu(lin.float()).to(BF), "relu": F.relu(lin)}[epi].float()
+                amp = lin.float().abs() + 2.0 ** -9 * T.float()
+        torch.cuda.synchronize()
+        o = o16.float()
+        if not torch.isfinite(o).all():
+            fails.append(tag + ": non-finite")
+        elif integer:
+            if not torch.equal(o, ref):
+                fails.append(tag + f": integer data not exact ({int((o != ref).sum())} cells)")
+        else:
+            # as gemm_case, + the MFMA's own accumulation error (measured <= 2^-17 of sum|a||w|; 2^-9 x 4 x 2^-8 = 2^-15 of it is allowed, as tests/test_fp8_gpu.py ACC_TOL)
+            err = (o - ref).abs()
+            bad = err > 4 * 2.0 ** -8 * amp + 1e-6
+            if bad.any():
+                fails.append(tag + f": {int(bad.sum())} cells beyond the bound (worst {float((err / (amp + 1e-9)).max()):.4f})")
+    except Exception as e:  # noqa: BLE001
+        fails.append(tag + f": {type(e).__name__}: {e}")
+
+
+def folded_case():
+    """a norm folded into the GEMM (round 4, mjv.h row_scale): LayerNorm into bias / bias+GELU, RMSNorm into SiLU-mul, every tile kernel"""
+    M = rng.choice([17, 64, 80, 256, 300, 513, 1025, rng.randrange(1, 2500), 256 * rng.randrange(1, 12) + rng.choice([0, 64])])
+    K = 64 * rng.choice([2, 3, 4, 8, 16, 32])
+    N = 32 * rng.choice([1, 2, 8, 9, 16, 32])
+    tile = rng.choice([0, 64, 128, 256])
+    kind = rng.choice(["ln_bias", "ln_gelu", "rms_silu"])
+    x = (torch.randn(M, K, device=dev) * 1.5 + rng.choice([0.0, 0.4])).to(BF)
+    gain = (torch.randn(K, device=dev) * 0.2 + 1.0).to(BF)
+    w = (torch.randn(N, K, device=dev) * (1.5 / K ** 0.5)).to(BF)
+    tag = f"folded M={M} N={N} K={K} kind={kind} tile={tile}"
+    try:
+        wf = (w.float() * gain.float()[None, :]).to(BF)
+        rstd = torch.empty(ops.padded_rows(M), dtype=torch.float32, device=dev)
+        xd = x.double()
+        if kind == "rms_silu":
+            ops.row_stats(x, rstd, None, 1e-5)
+            r = 1.0 / torch.sqrt((xd * xd).mean(1, keepdim=True) + 1e-5)
+            ff = N // 2
+            w13f = torch.stack([wf[:ff].view(ff // 16, 16, K), wf[ff:].view(ff // 16, 16, K)], dim=1).reshape(N, K).contiguous()
+            out = torch.empty(M, ff, dtype=BF, device=dev)
+            ops.gemm(x, w13f, out, ops.EPI_SILU_MUL, folded_norm=(rstd,), tile=tile)
+            g = (r * (xd @ wf[:ff].double().t())).float().to(BF)
+            u = (r * (xd @ wf[ff:].double().t())).float().to(BF)
+            ref = (F.silu(g) * u).float()
+            amp = 2.2 * g.float().abs() * u.float().abs() + ref.abs()
+        else:
+            beta, b = (torch.randn(K, device=dev) * 0.2).to(BF), (torch.randn(N, device=dev) * 0.1).to(BF)
+            mrs = torch.empty_like(rstd)
+            ops.row_stats(x, rstd, mrs, 1e-6)
+            colsum, bias2 = wf.float().sum(1), w.float() @ beta.float() + b.float()
+            pad = lambda v: torch.cat([v, torch.zeros(ops.padded_rows(N) - N, device=dev)])   # noqa: E731
+            mean = xd.mean(1, keepdim=True)
+            r = 1.0 / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6)
+            lin = (r * (xd @ wf.double().t() - mean * colsum.double()[None, :]) + bias2.double()[None, :]).float().to(BF)
+            out = torch.empty(M, N, dtype=BF, device=dev)
+            ops.gemm(x, wf, out, ops.EPI_BIAS_GELU if kind == "ln_gelu" else ops.EPI_BIAS, folded_norm=(rstd, mrs, pad(colsum), pad(bias2)), tile=tile)
+            ref = (F.gelu(lin.float()).to(BF) if kind == "ln_gelu" else lin).float()
+            amp = lin.float().abs() + (r * (xd.abs() @ wf.double().abs().t())).float() * 2.0 ** -12
+        torch.cuda.synchronize()
+        err = (out.float() - ref).abs()
+        # (+ an absolute floor for cells whose gate AND up value - or whose Linear - cancel to ~1e-3: summation-order noise of unit-scale sums)
+        bad = err > 4 * 2.0 ** -8 * amp + 2e-5
+        if not torch.isfinite(out.float()).all() or bad.any():
+            fails.append(tag + f": {int(bad.sum())} cells beyond the bound (worst {float((err / (amp + 1e-9)).max()):.4f})")
+    except Exception as e:  # noqa: BLE001
+        fails.append(tag + f": {type(e).__name__}: {e}")
+
+
+t0 = time.time()
+n_g = n_a = n_8 = n_f = 0
+while time.time() - t0 < budget:
+    x_ = rng.random()
+    if x_ < 0.35:
+        gemm_case(); n_g += 1
+    elif x_ < 0.65:
         attn_case(); n_a += 1
+    elif x_ < 0.85:
+        gemm8_case(); n_8 += 1
+    else:
+        folded_case(); n_f += 1
     if len(fails) > 30:
         break
-print(f"{n_g} GEMM cases, {n_a} attention cases in {time.time() - t0:.0f} s (seed {seed}): {len(fails)} failures")
+print(f"{n_g} GEMM cases, {n_a} attention cases, {n_8} MXFP8 GEMM cases, {n_f} folded-norm cases in {time.time() - t0:.0f} s (seed {seed}): {len(fails)} failures")
 for f in fails:
     print("FAIL", f)
 sys.exit(1 if fails else 0)
