@@ -689,14 +689,14 @@ class InternVLChatRewardModeling(nn.Module):
         if self.debug_probes is not None:
             self.debug_probes["vit_embeds"] = hidden[img_rows.long()].clone().view(tiles, -1, hidden.shape[1])
 
-    def _vit_layer(self, layer, x, h, qkv, f, cu, T, li: int = -1):
+    def _vit_layer(self, layer, x, h, qkv, f, cu, T, li: int):
         """One InternVisionEncoderLayer (modeling_intern_vit.py:283-295) in place on the packed rows ``x`` [tiles * T, dim];
         ``h`` / ``qkv`` / ``f`` are scratch buffers of [rows, dim] / [rows, 3 dim] / [rows, intermediate].  ``li``: the layer's
         index (the mxfp8 FFN path looks its quantised weights up by it)."""
         vc = self.config.vision_config
         dim, H = vc.hidden_size, vc.num_attention_heads
         scale = (dim // H) ** -0.5
-        fold = self._derived["vit_fold"][li] if self.norm_fusion and li >= 0 else None
+        fold = self._derived["vit_fold"][li] if self.norm_fusion else None
         if fold is not None:
             rows, dev = x.shape[0], x.device
             rstd = self._buf("vit_rstd", 1, ops.padded_rows(rows), dev, dtype=torch.float32).view(-1)
