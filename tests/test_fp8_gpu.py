@@ -92,7 +92,7 @@ def test_norms_mxfp8_equal_bf16_norm_then_quantise(cuda, rows, dim):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
-# Measured (tools/fp8_debug.py, profiles/r04_c_mfma_fp8_accumulation.txt): the sum of the 128 products INSIDE one
+# Measured (tools/mfma_fp8_accumulation.py, profiles/r04_c_mfma_fp8_accumulation.txt): the sum of the 128 products INSIDE one
 # v_mfma_scale_f32_16x16x128_f8f6f4 is not a sequential fp32 sum - on random operands it is off by up to 2^-17 of sum|a||w|
 # (K = 128; 2^-19 at K = 1024), against 2^-24.7 for torch's fp32 matmul.  An output with heavy cancellation (|sum| << sum|a||w|)
 # is therefore several bf16 ulps of ITSELF away from the exact sum although every product is exact.  The tolerance of the
