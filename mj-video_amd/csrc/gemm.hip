@@ -44,7 +44,7 @@ MJV_DEV float gelu_lut(float xf, const u16* tab) {
   const unsigned rel = mag - MJV_GELU_LO;                       // wraps to a huge value below the table
   const unsigned sgn = (unsigned)((int)u >> 31);                // all ones for x < 0
   const bool in_tab = rel < (unsigned)MJV_GELU_R;
-  const unsigned idx = in_tab ? rel + (sgn & MJV_GELU_R) : 0u;
+  const unsigned idx = in_tab ? rel + (sgn & MJV_GELU_NEG_OFF) : 0u;
   const unsigned t = tab[idx];
   const unsigned big = sgn ? 0x80000000u : u;                   // beyond the table: x for x > 0, -0 for x < 0
   const unsigned small = __float_as_uint(0.5f * xf);            // below the table: x / 2
@@ -526,6 +526,41 @@ constexpr int ST_OFF = LDS_BYTES;
 constexpr int LDS_BYTES_FUSE = LDS_BYTES + 4096;
 static_assert(ST_OFF % 16 == 0 && LDS_BYTES_FUSE <= 160 * 1024, "LDS budget (fused norm)");
 
+// GELU kernels (round 4): the table's two sign halves sit 64 KiB apart - x > 0 at LDS byte 0, x < 0 at byte 65536 - so that
+// the gather address is the rounded value's own bit pattern: (fp32 bits >> 15) - 2 LO = 65536 sign + 2 (magnitude - LO), two
+// vector instructions where the contiguous table took five (magnitude, -LO, sign mask, & R, +) and a per-element range
+// compare.  A 16-KiB pipeline slot is given up at each of the two addresses (the eight half-tiles use slots 1-3 and 5-9 of the
+// ten the 160 KiB hold), the folded-norm vectors go behind the first table, and the staged output tile - which no longer has
+// 132 contiguous KiB - is split into rows 0..100 below the second table and rows 101..255 above it.
+constexpr int G_NEG = 65536;
+constexpr int G_ST = 7680;                       // FUSE vectors (4 KiB), behind the 7 680-byte table half
+constexpr int G_A0 = G_ST + 4096, G_AROWS = (G_NEG - G_A0) / EPI_PITCH;     // rows 0 .. G_AROWS - 1
+constexpr int G_B0 = G_NEG + 7680;                                            // rows G_AROWS .. 255
+constexpr int LDS_BYTES_G = 160 * 1024;
+static_assert(MJV_GELU_NEG_OFF * 2 <= G_ST && G_A0 + G_AROWS * EPI_PITCH <= G_NEG && G_NEG + MJV_GELU_NEG_OFF * 2 <= G_B0 &&
+              G_B0 + (256 - G_AROWS) * EPI_PITCH <= LDS_BYTES_G && G_A0 % 16 == 0 && G_B0 % 16 == 0, "GELU LDS map");
+template <bool GL>
+MJV_DEV int half_off(int idx) {   // LDS byte offset of pipeline half-tile idx = (K-tile & 1) * 4 + {W0, W1, A0, A1}
+  return GL ? (idx + 1 + (idx >= 3 ? 1 : 0)) * HALF_BYTES : idx * HALF_BYTES;
+}
+template <bool GL>
+MJV_DEV int erow_off(int ml) {    // LDS byte offset of row ml of the staged output tile
+  return GL ? ml * EPI_PITCH + (ml < G_AROWS ? G_A0 : G_B0 - G_AROWS * EPI_PITCH) : ml * EPI_PITCH;
+}
+// general form of the table GELU on the split table (gelu_lut's logic; tab = LDS base)
+MJV_DEV float gelu_lut_split(float xf, const char* lds) {
+  const unsigned u = __float_as_uint(xf);
+  const unsigned mag = (u >> 16) & 0x7fffu;
+  const unsigned rel = mag - MJV_GELU_LO;
+  const unsigned sgn = (unsigned)((int)u >> 31);
+  const bool in_tab = rel < (unsigned)MJV_GELU_R;
+  const unsigned t = *(const u16*)(lds + (sgn & G_NEG) + (in_tab ? rel * 2 : 0u));
+  const unsigned big = sgn ? 0x80000000u : u;
+  const unsigned small = __float_as_uint(0.5f * xf);
+  const unsigned other = mag < MJV_GELU_LO ? small : big;
+  return __uint_as_float(in_tab ? (t << 16) : other);
+}
+
 // per-lane global source pointers of the two 1-KiB DMA pieces a wave issues for each of the four half-tiles
 // (W rows 0-127, W rows 128-255, A rows 0-127, A rows 128-255) at k = 0: the row clamp and the chunk swizzle are loop
 // invariant, so a stage is two {pointer + k offset, global_load_lds} pairs - the DMA issue sits in the load segment that
@@ -554,10 +589,10 @@ MJV_DEV void init_stage_ptrs(StagePtrs& sp, const GemmArgs& p, int m0, int n0, i
 }
 
 // stage half-tile WHICH of K-tile t (no-op past the last K-tile)
-template <int WHICH>
+template <int WHICH, bool GL = false>
 MJV_DEV void stage_half(const StagePtrs& sp, int t, int nk, char* smem, int wave) {
   if (t >= nk) return;
-  char* dst = smem + ((t & 1) * 4 + WHICH) * HALF_BYTES + wave * 2048;
+  char* dst = smem + half_off<GL>((t & 1) * 4 + WHICH) + wave * 2048;
   const int k0 = t * BK;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -603,6 +638,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   // VAR 7: split-K slice of a tile (workgroup b = tile b / split, slice b % split), as in the 128-tile kernel: the
   // accumulators go to the fp32 workspace as they sit in registers, splitk_finish256_kernel sums them in slice order
   constexpr bool SPLIT = VAR == 7;
+  constexpr bool GL = EPI == MJV_EPI_BIAS_GELU;      // the GELU kernels' LDS map (tables 64 KiB apart, see G_NEG)
+  constexpr int ST = GL ? G_ST : ST_OFF;             // where the folded-norm vectors sit
   const int tile_id = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x;
   const int slice = SPLIT ? (int)blockIdx.x % p.split : 0;
   tile_of_vblock(p, SPLIT ? (int)gridDim.x / p.split : (int)gridDim.x, tile_id, tm, tn);
@@ -680,12 +717,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // (older in the vmcnt queue than everything the counted waits below count): copied at the head of the epilogue it cost
     // a global round trip and a barrier per tile
     static_assert(MJV_GELU_TABLE_LEN % 8 == 0 && MJV_GELU_TABLE_LEN / 8 <= 1024, "two 16-byte chunks per thread cover the table");
+    // the two sign halves (MJV_GELU_NEG_OFF entries = 480 16-byte chunks each) to LDS bytes 0.. and 65536..: one
+    // instruction per half and wave, older in the vmcnt queue than every K-tile DMA the counted waits count
+    static_assert(MJV_GELU_NEG_OFF % 8 == 0 && MJV_GELU_NEG_OFF / 8 <= 8 * 64, "eight 64-lane instructions cover a table half");
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int chunk = (i * 8 + wave) * 64 + lane;
-      if (chunk < MJV_GELU_TABLE_LEN / 8)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const u32x4*)g_gelu_table + chunk),
-                                         (__attribute__((address_space(3))) void*)(smem + EPI_TILE_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
+      const int chunk = wave * 64 + lane;
+      if (chunk < MJV_GELU_NEG_OFF / 8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const u32x4*)(g_gelu_table + i * MJV_GELU_NEG_OFF) + chunk),
+                                         (__attribute__((address_space(3))) void*)(smem + i * G_NEG + wave * 1024), 16, 0, 0);
     }
   }
   if constexpr (SPLIT) {
@@ -694,14 +734,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) sp.src[which][i] += kt0 * BK;
   }
-  if constexpr (FUSE != 0) stage_fused_vectors(p, FUSE, m0, n0, smem, wave, lane, ST_OFF);
+  if constexpr (FUSE != 0) stage_fused_vectors(p, FUSE, m0, n0, smem, wave, lane, ST);
   // ---- prologue: K-tile 0 completely, W halves of K-tile 1
-  stage_half<0>(sp, 0, nk, smem, wave);
-  stage_half<1>(sp, 0, nk, smem, wave);
-  stage_half<2>(sp, 0, nk, smem, wave);
-  stage_half<3>(sp, 0, nk, smem, wave);
-  stage_half<0>(sp, 1, nk, smem, wave);
-  stage_half<1>(sp, 1, nk, smem, wave);
+  stage_half<0, GL>(sp, 0, nk, smem, wave);
+  stage_half<1, GL>(sp, 0, nk, smem, wave);
+  stage_half<2, GL>(sp, 0, nk, smem, wave);
+  stage_half<3, GL>(sp, 0, nk, smem, wave);
+  stage_half<0, GL>(sp, 1, nk, smem, wave);
+  stage_half<1, GL>(sp, 1, nk, smem, wave);
   // the 128 accumulator registers are zeroed HERE, under the first K-tile's flight time: left alone, the compiler sinks the
   // v_movs (256 of them: one set per side of the loop-entry branch) below the wait and the barriers, where they are 1-2 k
   // exposed cycles per tile
@@ -748,21 +788,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   // interval between issue and retire - group 0 retiring after its phase-II MFMAs, group 1 issuing at the head of its
   // phase-II MFMA segment - measured 0 ... -4 %: the retiring wait is not what the loop waits for.)
   for (int t = 0; t < nk; ++t) {
-    const char* abase = smem + ((t & 1) * 4 + a_half) * HALF_BYTES;
-    const char* wbase = smem + ((t & 1) * 4 + w_half) * HALF_BYTES;
+    const char* abase = smem + half_off<GL>((t & 1) * 4 + a_half);
+    const char* wbase = smem + half_off<GL>((t & 1) * 4 + w_half);
     MJV_LOAD_W(0)
     MJV_LOAD_W(1)
     MJV_LOAD_A(0)
-    stage_half<2>(sp, t + 1, nk, smem, wave);   // A rows 0-127 of K-tile t+1
-    stage_half<3>(sp, t + 1, nk, smem, wave);   // A rows 128-255 of K-tile t+1
+    stage_half<2, GL>(sp, t + 1, nk, smem, wave);   // A rows 0-127 of K-tile t+1
+    stage_half<3, GL>(sp, t + 1, nk, smem, wave);   // A rows 128-255 of K-tile t+1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MJV_BARRIER();
     MJV_MFMA(0, 0)
     MJV_MFMA(0, 1)
     MJV_BARRIER();
     MJV_LOAD_A(1)
-    stage_half<0>(sp, t + 2, nk, smem, wave);   // W rows 0-127 of K-tile t+2
-    stage_half<1>(sp, t + 2, nk, smem, wave);   // W rows 128-255 of K-tile t+2
+    stage_half<0, GL>(sp, t + 2, nk, smem, wave);   // W rows 0-127 of K-tile t+2
+    stage_half<1, GL>(sp, t + 2, nk, smem, wave);   // W rows 128-255 of K-tile t+2
     if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but the 2 half-tiles of t+2 issued last
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -808,8 +848,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   //         loads and stores (an 8-B-per-lane fragment store touches 16 rows x 32 B per instruction and ran the
   //         K = 1024 GEMMs at half speed).
   char* etile = smem;
-  u16* gtab = (u16*)(smem + EPI_TILE_BYTES);
-  // (the GELU table was copied to its LDS region - beyond the pipeline buffers - by the prologue's first DMA instructions)
+  // (the GELU table halves were copied to LDS bytes 0.. and 65536.. - around the pipeline buffers - by the prologue's first DMA instructions)
   constexpr int OUT_COLS = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
   // pass B geometry: 32 (16 for SiLU) lanes x 16 B = one output row per pass
   constexpr int LANES_PER_ROW = OUT_COLS / 8;          // 16-B chunks per output row
@@ -853,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   // lin(i, j, r) = acc * rs[i] + bq[r], bq = bias - row_shift[i] * col_shift (one more fma per element for a LayerNorm)
   float rs8[FUSE ? 8 : 1], rh8[FUSE == 2 ? 8 : 1];
   if constexpr (FUSE != 0) {
-    const float* st = (const float*)(smem + ST_OFF);
+    const float* st = (const float*)(smem + ST);
 #pragma unroll
     for (int i = 0; i < 8; ++i) rs8[i] = st[wr * 128 + i * 16 + l15];
     if constexpr (FUSE == 2) {
@@ -869,8 +908,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                    __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
     f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FUSE == 2) {
-      const f32x4 bq = *(const f32x4*)(smem + ST_OFF + 3072 + nl * 4);
-      c4 = *(const f32x4*)(smem + ST_OFF + 2048 + nl * 4);
+      const f32x4 bq = *(const f32x4*)(smem + ST + 3072 + nl * 4);
+      c4 = *(const f32x4*)(smem + ST + 2048 + nl * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) b4[r] = bq[r];
     }
@@ -887,29 +926,41 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       // Fast path = every element of every lane of the wave inside the table (|x| in [2^-23, 5.56): all but one activation
       // in ~10^7 for unit-scale inputs): magnitude - LO + sign * R indexes the table directly; otherwise the general form
       // (x/2 below the table, x or -0 above).
-      unsigned ubs[8][4], idx[8][4];
-      bool all_in = true;
+      // (round 4) the gather address is the rounded value's own bit pattern: (bits >> 15) - 2 LO = 65536 sign + 2 (|x| bits - LO).
+      // Fast path = every element of every lane of the wave inside the table, decided from the running min / max of |x| (the
+      // magnitudes' order is the patterns' order); otherwise the general form (x / 2 below the table, x or -0 above).
+      unsigned ubs[8][4];
+      float amax = 0.f, amin = __uint_as_float(0x7f000000u);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          ubs[i][r] = __float_as_uint(rbf(lin(i, j, r)));
-          const unsigned rel = ((ubs[i][r] >> 16) & 0x7fffu) - MJV_GELU_LO;
-          all_in = all_in && (rel < (unsigned)MJV_GELU_R);
-          idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_R;
+          const float xr = rbf(lin(i, j, r));
+          ubs[i][r] = __float_as_uint(xr);
+          amax = fmaxf(amax, fabsf(xr));
+          amin = fminf(amin, fabsf(xr));
         }
+      const bool all_in = amin >= __uint_as_float((unsigned)MJV_GELU_LO << 16) && amax < __uint_as_float((unsigned)MJV_GELU_HI << 16);
       if (__all(all_in)) {
         unsigned t[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) t[i][r] = gtab[idx[i][r]];
+          for (int r = 0; r < 4; ++r) {
+#if defined(MJV_GELU_PROBE) && MJV_GELU_PROBE == 1      // measurement only (wrong values): conflict-free addresses
+            t[i][r] = *(const u16*)(smem + (((ubs[i][r] >> 15) & 0x1f80u) | (lane * 2)));
+#elif defined(MJV_GELU_PROBE) && MJV_GELU_PROBE == 2    // measurement only (wrong values): no gather at all
+            t[i][r] = ubs[i][r] >> 16;
+#else
+            t[i][r] = *(const u16*)(smem + ((ubs[i][r] >> 15) - 2u * MJV_GELU_LO));
+#endif
+          }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int ml = wr * 128 + i * 16 + l15;
           // table entries are bf16 bit patterns: two of them side by side are the packed pair as it is
           const u32x2 o = {t[i][0] | (t[i][1] << 16), t[i][2] | (t[i][3] << 16)};
-          *(u32x2*)(etile + ml * EPI_PITCH + nl * 2) = o;
+          *(u32x2*)(smem + erow_off<GL>(ml) + nl * 2) = o;
         }
       } else {
 #pragma unroll
@@ -917,9 +968,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
           const int ml = wr * 128 + i * 16 + l15;
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_lut(__uint_as_float(ubs[i][r]), gtab);
+          for (int r = 0; r < 4; ++r) v[r] = gelu_lut_split(__uint_as_float(ubs[i][r]), smem);
           const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-          *(u32x2*)(etile + ml * EPI_PITCH + nl * 2) = o;
+          *(u32x2*)(smem + erow_off<GL>(ml) + nl * 2) = o;
         }
       }
       continue;
@@ -944,7 +995,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         col = nl;
       }
       const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};   // one v_cvt_pk_bf16_f32 per pair
-      *(u32x2*)(etile + ml * EPI_PITCH + col * 2) = o;
+      *(u32x2*)(etile + erow_off<GL>(ml) + col * 2) = o;
     }
   }
   const unsigned long long t_passA = stamp();
@@ -1021,7 +1072,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // loop was {ds_read, s_waitcnt lgkmcnt(0), store} sixteen times, a full LDS latency per row
     u32x4 vals[PASSES];
 #pragma unroll
-    for (int it = 0; it < PASSES; ++it) vals[it] = *(const u32x4*)(etile + (it * ROWS_PER_PASS + ml0) * EPI_PITCH + c8 * 2);
+    for (int it = 0; it < PASSES; ++it) vals[it] = *(const u32x4*)(etile + erow_off<GL>(it * ROWS_PER_PASS + ml0) + c8 * 2);
 
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
@@ -1378,7 +1429,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
                 ubs[i][r] = __float_as_uint(rbf(lin(4 * hf + i, j, r)));
                 const unsigned rel = ((ubs[i][r] >> 16) & 0x7fffu) - MJV_GELU_LO;
                 all_in = all_in && (rel < (unsigned)MJV_GELU_R);
-                idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_R;
+                idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_NEG_OFF;
               }
             if (__all(all_in)) {
               unsigned t[4][4];
@@ -1496,6 +1547,7 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
     hipLaunchKernelGGL((t64::gemm_skinny_kernel<EPI, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), t64::Cfg<2>::LDS_BYTES, s, a);
     return mjv_check_launch("gemm_bf16");
   }
+  constexpr int LDS1 = EPI == MJV_EPI_BIAS_GELU ? t256::LDS_BYTES_G : t256::LDS_BYTES;   // (the GELU kernels' map uses all 160 KiB)
   // the dynamic-LDS limit is a per-device function attribute: set it once on every device this instantiation runs on
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
@@ -1504,11 +1556,11 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
   if (!(attr_done.load(std::memory_order_acquire) & bit)) {
     (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)t128::gemm128_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, t128::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
 #ifdef MJV_BENCH
-    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+    (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
 #endif
     (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<MJV_EPI_BIAS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     // (the persistent form is instantiated for the three epilogues that launch it - ADVICE r3: the LayerScale / GELU
@@ -1517,7 +1569,8 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
       (void)hipFuncSetAttribute((const void*)t256::gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES);
     // a norm folded into the GEMM: LayerNorm into the ViT's qkv / fc1 (bias epilogues), RMSNorm into wqkv / w1|w3
     if constexpr (EPI == MJV_EPI_BIAS || EPI == MJV_EPI_BIAS_GELU)
-      (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES_FUSE);
+      (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                EPI == MJV_EPI_BIAS_GELU ? t256::LDS_BYTES_G : t256::LDS_BYTES_FUSE);
     if constexpr (EPI == MJV_EPI_SILU_MUL || EPI == MJV_EPI_ROPE_QKV)
       (void)hipFuncSetAttribute((const void*)t256::gemm256_kernel<EPI, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES_FUSE);
     if constexpr (EPI == MJV_EPI_BIAS)
@@ -1543,7 +1596,8 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
             return mjv_check_launch("gemm_bf16");
           }
         }
-        hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0, WANT>), dim3(tiles), dim3(512), t256::LDS_BYTES_FUSE, s, a);
+        hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0, WANT>), dim3(tiles), dim3(512),
+                           EPI == MJV_EPI_BIAS_GELU ? t256::LDS_BYTES_G : t256::LDS_BYTES_FUSE, s, a);
         return mjv_check_launch("gemm_bf16");
       }
     }
@@ -1563,11 +1617,11 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
 #ifdef MJV_BENCH
     else if (MJV_TUNE(variant) == 6) {
       a.ws = (float*)MJV_TUNE(stamp_buffer);
-      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 6>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 6>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS1, s, a);
     } else if (MJV_TUNE(variant) == 4)
-      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS1, s, a);
     else if (MJV_TUNE(variant) == 3)
-      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS1, s, a);
 #endif
     else {
       // persistent form (one workgroup per CU walks the tiles, next tile's first K-tile prefetched under the epilogue) when the
@@ -1589,7 +1643,7 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
           return mjv_check_launch("gemm_bf16");
         }
       }
-      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0>), dim3(a.tiles_m * a.tiles_n), dim3(512), t256::LDS_BYTES, s, a);
+      hipLaunchKernelGGL((t256::gemm256_kernel<EPI, 0>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS1, s, a);
     }
   } else {
     a.tiles_m = (a.M + 127) / 128;

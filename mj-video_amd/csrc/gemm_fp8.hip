@@ -59,7 +59,7 @@ MJV_DEV float gelu_lut(float xf, const u16* tab) {
   const unsigned rel = mag - MJV_GELU_LO;
   const unsigned sgn = (unsigned)((int)u >> 31);
   const bool in_tab = rel < (unsigned)MJV_GELU_R;
-  const unsigned idx = in_tab ? rel + (sgn & MJV_GELU_R) : 0u;
+  const unsigned idx = in_tab ? rel + (sgn & MJV_GELU_NEG_OFF) : 0u;
   const unsigned t = tab[idx];
   const unsigned big = sgn ? 0x80000000u : u;
   const unsigned small = __float_as_uint(0.5f * xf);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
           ubs[i][r] = __float_as_uint(rbf(acc[i][j][r] + b4[r]));
           const unsigned rel = ((ubs[i][r] >> 16) & 0x7fffu) - MJV_GELU_LO;
           all_in = all_in && (rel < (unsigned)MJV_GELU_R);
-          idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_R;
+          idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_NEG_OFF;
         }
       if (__all(all_in)) {
         unsigned t[8][4];

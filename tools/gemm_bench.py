@@ -11,14 +11,17 @@ from mj_video_amd import ops
 dev = torch.device("cuda:0")
 WS = None
 BF = torch.bfloat16
+WSTD = float(os.environ.get("MJV_BENCH_WSTD", 0.05))
 
 
 def bench(M, N, K, epi, tile, iters=20):
     a = torch.randn(M, K, device=dev, dtype=torch.float32).to(BF)
-    w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.05).to(BF)
+    # MJV_BENCH_WSTD=0.02 keeps every pre-activation of the GELU shapes inside the table's range (|x| < 5.56), the wave-uniform fast
+    # path of pass A - what the model's fc1 sees; the default 0.05 (sigma 1.9 with the bias) sends nearly every wave down the general path
+    w = (torch.randn(N, K, device=dev, dtype=torch.float32) * WSTD).to(BF)
     nout = N // 2 if epi == ops.EPI_SILU_MUL else N
     out = torch.empty(M, nout, device=dev, dtype=BF)
-    bias = torch.randn(N, device=dev).to(BF) if epi not in (ops.EPI_SILU_MUL,) else None
+    bias = (torch.randn(N, device=dev) * (WSTD / 0.05)).to(BF) if epi not in (ops.EPI_SILU_MUL,) else None
     res = torch.randn(M, nout, device=dev).to(BF) if epi == ops.EPI_SCALE_RES else None
     scale = torch.randn(N, device=dev).to(BF) if epi == ops.EPI_SCALE_RES else None
     if tile == 9000:      # automatic tile choice with a workspace, 256-tile split-K switched off (A/B against 5000)
