@@ -517,7 +517,8 @@ constexpr int PIPE_BYTES = 8 * HALF_BYTES;  // 2 K-tiles x {W0, W1, A0, A1}
 constexpr int EPI_PITCH = 256 * 2 + 16;     // bf16 output tile staged for coalesced stores: 528-B rows (conflict-free)
 constexpr int EPI_TILE_BYTES = 256 * EPI_PITCH;
 constexpr int GELU_BYTES = MJV_GELU_TABLE_LEN * 2;
-constexpr int LDS_BYTES = EPI_TILE_BYTES + GELU_BYTES;  // 140704 B >= PIPE_BYTES: one workgroup per CU either way
+constexpr int LDS_BYTES = EPI_TILE_BYTES + GELU_BYTES;  // 150 528 B >= PIPE_BYTES: one workgroup per CU either way (the table's
+                                                        // place in the persistent kernel's map; the one-tile GELU kernel has its own, below)
 static_assert(LDS_BYTES >= PIPE_BYTES && LDS_BYTES <= 160 * 1024 && EPI_TILE_BYTES % 16 == 0, "LDS budget");
 // FUSE kernels (a norm folded into this GEMM, mjv.h "row_scale"): the tile's 256 row_scale / row_shift / col_shift / bias_f32
 // floats, 1 KiB each, past the GELU table - fetched by LDS-DMA in the prologue (older than every K-tile DMA the counted waits
@@ -946,15 +947,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-#if defined(MJV_GELU_PROBE) && MJV_GELU_PROBE == 1      // measurement only (wrong values): conflict-free addresses
-            t[i][r] = *(const u16*)(smem + (((ubs[i][r] >> 15) & 0x1f80u) | (lane * 2)));
-#elif defined(MJV_GELU_PROBE) && MJV_GELU_PROBE == 2    // measurement only (wrong values): no gather at all
-            t[i][r] = ubs[i][r] >> 16;
-#else
-            t[i][r] = *(const u16*)(smem + ((ubs[i][r] >> 15) - 2u * MJV_GELU_LO));
-#endif
-          }
+          for (int r = 0; r < 4; ++r) t[i][r] = *(const u16*)(smem + ((ubs[i][r] >> 15) - 2u * MJV_GELU_LO));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int ml = wr * 128 + i * 16 + l15;
