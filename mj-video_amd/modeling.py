@@ -341,6 +341,10 @@ class InternVLChatRewardModeling(nn.Module):
         # quantised once in _prepare, activations in the producing kernel (norm / GELU / SiLU-mul epilogue).  Not a drop-in for
         # the reference's bf16 numbers: held to oracle/ref_fp8.py and reported with its own tolerance.
         self.ffn_format = "bf16"
+        # MEASUREMENT ONLY (tools/fp8_attn_side_study.py; never set by the product): with ffn_format "mxfp8", also run the four
+        # attention-side Linears (qkv / proj, wqkv / wo) on MXFP8 operands through UNFUSED launches (standalone quantiser, standalone
+        # RoPE) - the numerics an all-Linear fp8 path would have, to decide whether its fused kernels are worth writing
+        self._exp_fp8_attn_side = False
         # The reference ships two attention numerics.  "flash" (default since round 4): fp32 softmax on UNROUNDED scores - its
         # flash-attention path (modeling_intern_vit.py:229-244, modeling_internlm2.py:437-561), the one it runs on a GPU;
         # score_round_mode 2 of the C ABI.  "eager": the scores rounded to bf16 before the softmax exactly where its eager path
@@ -393,7 +397,7 @@ class InternVLChatRewardModeling(nn.Module):
 
     def _signature(self):
         ps = list(self.parameters())
-        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps) + (self.ffn_format, bool(self.norm_fusion))
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps) + (self.ffn_format, bool(self.norm_fusion), bool(self._exp_fp8_attn_side))
 
     def _prepare(self, device):
         """One-time weight layout conversion (redone if any parameter storage/version changed):
@@ -447,6 +451,11 @@ class InternVLChatRewardModeling(nn.Module):
             d["fc2_8"] = [ops.quantize_mxfp8(l.mlp.fc2.weight) for l in self.model.vision_model.encoder.layers]
             d["w13_8"] = [ops.quantize_mxfp8(w) for w in w13]
             d["w2_8"] = [ops.quantize_mxfp8(l.feed_forward.w2.weight) for l in self.model.language_model.model.layers]
+            if self._exp_fp8_attn_side:
+                d["qkv_8"] = [ops.quantize_mxfp8(l.attn.qkv.weight) for l in self.model.vision_model.encoder.layers]
+                d["proj_8"] = [ops.quantize_mxfp8(l.attn.proj.weight) for l in self.model.vision_model.encoder.layers]
+                d["wqkv_8"] = [ops.quantize_mxfp8(l.attention.wqkv.weight) for l in self.model.language_model.model.layers]
+                d["wo_8"] = [ops.quantize_mxfp8(l.attention.wo.weight) for l in self.model.language_model.model.layers]
         offs, idx = [0], []
         for _, crit in self.aspect2criteria.items():
             idx += list(crit)
@@ -697,6 +706,7 @@ class InternVLChatRewardModeling(nn.Module):
         dim, H = vc.hidden_size, vc.num_attention_heads
         scale = (dim // H) ** -0.5
         fold = self._derived["vit_fold"][li] if self.norm_fusion else None
+        exp8 = self._exp_fp8_attn_side and self.ffn_format == "mxfp8" and fold is None
         if fold is not None:
             rows, dev = x.shape[0], x.device
             rstd = self._buf("vit_rstd", 1, ops.padded_rows(rows), dev, dtype=torch.float32).view(-1)
@@ -704,12 +714,20 @@ class InternVLChatRewardModeling(nn.Module):
             ops.row_stats(x, rstd, mrs, vc.layer_norm_eps)
             wq, cq, bq = fold["qkv"]
             ops.gemm(x, wq, qkv, EPI_BIAS, folded_norm=(rstd, mrs, cq, bq))
+        elif exp8:
+            h8a = self._buf8("vit_h8a", x.shape[0], dim, x.device)
+            ops.layernorm_mxfp8(x, layer.norm1.weight, layer.norm1.bias, h8a, vc.layer_norm_eps)
+            ops.gemm(h8a, self._derived["qkv_8"][li], qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
         else:
             ops.layernorm(x, layer.norm1.weight, layer.norm1.bias, h, vc.layer_norm_eps)
             ops.gemm(h, layer.attn.qkv.weight, qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
         ops.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], h, cu, T, H, 1, 64, False, scale,
                       2 if self.attention_scores == "flash" else 0)
-        ops.gemm(h, layer.attn.proj.weight, x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
+        if exp8:
+            a8 = ops.quantize_mxfp8(h, out=self._buf8("vit_a8", x.shape[0], dim, x.device))
+            ops.gemm(a8, self._derived["proj_8"][li], x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
+        else:
+            ops.gemm(h, layer.attn.proj.weight, x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
         if self.ffn_format == "mxfp8":
             # norm2 -> fc1 (+GELU) -> fc2 on MXFP8 operands: the norm and the GELU epilogue write e4m3 + block scales
             d = self._derived
@@ -798,12 +816,18 @@ class InternVLChatRewardModeling(nn.Module):
             if only_layer is not None and li != only_layer:   # (run_llm_layer: one layer on given rows)
                 continue
             lfold = d["llm_fold"][li] if self.norm_fusion else None
+            exp8 = self._exp_fp8_attn_side and self.ffn_format == "mxfp8" and lfold is None
             # wqkv with the rotary embedding + GQA de-interleave in its epilogue: q / k go (rotated) to their own buffers,
             # v stays in its columns of qkv (modeling_internlm2.py:359-381)
             if lfold is not None:
                 rstd = self._buf("llm_rstd", 1, ops.padded_rows(n), dev, dtype=torch.float32).view(-1)
                 ops.row_stats(x, rstd, None, lc.rms_norm_eps)
                 ops.gemm(x, lfold["wqkv"], qkv, EPI_ROPE_QKV, rope=(cos, sin, positions, q, k, G), folded_norm=(rstd,))
+            elif exp8:
+                h8a = self._buf8("llm_h8a", n, hdim, dev)
+                ops.rmsnorm_mxfp8(x, layer.attention_norm.weight, h8a, lc.rms_norm_eps)
+                ops.gemm(h8a, d["wqkv_8"][li], qkv, EPI_BIAS)
+                ops.rope_split(qkv, q, k, cos, sin, positions, KV, G)
             else:
                 ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
                 ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_ROPE_QKV, rope=(cos, sin, positions, q, k, G))
@@ -819,10 +843,16 @@ class InternVLChatRewardModeling(nn.Module):
                 act_s = self._buf("llm_act_sel", ns, ff, dev)
                 ops.embed_gather(sel_rows, hn, att_s, -1)     # row gathers (table = activation rows)
                 ops.embed_gather(sel_rows, x, x_s, -1)
-                ops.gemm(att_s, layer.attention.wo.weight, x_s, EPI_SCALE_RES, res=x_s)
+                if exp8:
+                    ops.gemm(ops.quantize_mxfp8(att_s), d["wo_8"][li], x_s, EPI_SCALE_RES, res=x_s)
+                else:
+                    ops.gemm(att_s, layer.attention.wo.weight, x_s, EPI_SCALE_RES, res=x_s)
                 self._llm_ffn(d, li, layer, x_s, hn_s, act_s, "sel")
                 return x_s
-            ops.gemm(hn, layer.attention.wo.weight, x, EPI_SCALE_RES, res=x)
+            if exp8:
+                ops.gemm(ops.quantize_mxfp8(hn, out=self._buf8("llm_a8a", n, hdim, dev)), d["wo_8"][li], x, EPI_SCALE_RES, res=x)
+            else:
+                ops.gemm(hn, layer.attention.wo.weight, x, EPI_SCALE_RES, res=x)
             self._llm_ffn(d, li, layer, x, hn, act, "all")
             if self.debug_probes is not None:
                 self.debug_probes[f"llm_layer{li}"] = x.clone()
