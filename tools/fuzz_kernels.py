@@ -233,16 +233,16 @@ def gemm8_case():
             g = (aq @ wq[:nout].t()).float().to(BF)
             u = (aq @ wq[nout:].t()).float().to(BF)
             ref = (F.silu(g) * u).float()
-            amp = 2.2 * g.float().abs() * u.float().abs() + ref.abs() + 2.0 ** -9 * (aq.abs() @ wq[:nout].abs().t() + aq.abs() @ wq[nout:].abs().t()).float() * (g.float().abs() + u.float().abs() + 1)
+            amp = 2.2 * g.float().abs() * u.float().abs() + ref.abs() + 2.0 ** -8 * (aq.abs() @ wq[:nout].abs().t() + aq.abs() @ wq[nout:].abs().t()).float() * (g.float().abs() + u.float().abs() + 1)
         else:
             lin = lin64.float().to(BF)
             if epi == "scale_res":
                 t1 = lin.float()
                 ref = (res.float() + (t1 * ls.float()).to(BF).float()).to(BF).float()
-                amp = res.float().abs() + 2 * (t1 * ls.float()).abs() + 2.0 ** -9 * T.float() * (1 + ls.float().abs())
+                amp = res.float().abs() + 2 * (t1 * ls.float()).abs() + 2.0 ** -8 * T.float() * (1 + ls.float().abs())
             else:
                 ref = {"bias": lin, "nobias": lin, "gelu": F.gelu(lin.float()).to(BF), "relu": F.relu(lin)}[epi].float()
-                amp = lin.float().abs() + 2.0 ** -9 * T.float()
+                amp = lin.float().abs() + 2.0 ** -8 * T.float()
         torch.cuda.synchronize()
         o = o16.float()
         if not torch.isfinite(o).all():
@@ -251,7 +251,9 @@ def gemm8_case():
             if not torch.equal(o, ref):
                 fails.append(tag + f": integer data not exact ({int((o != ref).sum())} cells)")
         else:
-            # as gemm_case, + the MFMA's own accumulation error (measured <= 2^-17 of sum|a||w|; 2^-9 x 4 x 2^-8 = 2^-15 of it is allowed, as tests/test_fp8_gpu.py ACC_TOL)
+            # as gemm_case, + the MFMA's own accumulation error: 4 x 2^-8 x 2^-8 = 2^-14 of sum|a||w| inside amp (tests/test_fp8_gpu.py ACC_TOL: the measured
+            # tail over 5e8 outputs reaches 2^-14.9; the 2^-15 this line allowed until the end of round 4 was exceeded by ONE output
+            # in a 1000-s run - 3.7e11 outputs)
             err = (o - ref).abs()
             bad = err > 4 * 2.0 ** -8 * amp + 1e-6
             if bad.any():
