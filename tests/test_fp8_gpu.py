@@ -295,6 +295,23 @@ def test_model_mxfp8_deterministic_and_reprepares(cuda):
         model.set_ffn_format("int4")
 
 
+def test_attention_side_mxfp8_study_flag(cuda):
+    """``model._exp_fp8_attn_side`` - the measurement flag behind tools/fp8_attn_side_study.py (MXFP8 on qkv / proj, wqkv / wo too,
+    through unfused launches; DESIGN "Why the fp8 path stops at the FFN") - keeps working: finite scores that differ from the
+    FFN-only path, the FFN-only result bit for bit again once cleared, and a deviation from bf16 of the same order as the FFN path's"""
+    cfg, sd, model, px, ids, mask = _tiny_model_and_batch(cuda, seed=23)
+    run = lambda: model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda)).score.float().clone()   # noqa: E731
+    bf = run()
+    ffn = model.set_ffn_format("mxfp8") and run()
+    model._exp_fp8_attn_side = True
+    allq = run()
+    model._exp_fp8_attn_side = False
+    back = run()
+    model.set_ffn_format("bf16")
+    assert torch.isfinite(allq).all() and not torch.equal(allq, ffn) and torch.equal(back, ffn)
+    assert (allq - bf).abs().max().item() <= 10.0 * max((ffn - bf).abs().max().item(), 1e-2)
+
+
 @pytest.mark.parametrize("tower,layer", [("vit", 0), ("vit", 23), ("llm", 0), ("llm", 23)])
 def test_single_layer_mxfp8_at_production_shape(cuda, tower, layer):
     """ONE layer at MJ-VIDEO-2B dims and the headline sequence lengths (2 x 1025 x 1024 vision rows, 1 x 2186 x 2048 language
