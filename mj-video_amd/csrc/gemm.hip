@@ -714,10 +714,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   StagePtrs sp;
   init_stage_ptrs(sp, p, m0, n0, wave, lane);
   if constexpr (EPI == MJV_EPI_BIAS_GELU) {
-    // the GELU table (13 KB) goes to its LDS region past the pipeline buffers by LDS-DMA, issued before the first K-tile
-    // (older in the vmcnt queue than everything the counted waits below count): copied at the head of the epilogue it cost
-    // a global round trip and a barrier per tile
-    static_assert(MJV_GELU_TABLE_LEN % 8 == 0 && MJV_GELU_TABLE_LEN / 8 <= 1024, "two 16-byte chunks per thread cover the table");
+    // the GELU table (15 KB) goes to its two LDS windows - pipeline slots 0 and 4, which the K-tiles never use - by LDS-DMA, issued
+    // before the first K-tile (older in the vmcnt queue than everything the counted waits below count): copied at the head of the
+    // epilogue it cost a global round trip and a barrier per tile
     // the two sign halves (MJV_GELU_NEG_OFF entries = 480 16-byte chunks each) to LDS bytes 0.. and 65536..: one
     // instruction per half and wave, older in the vmcnt queue than every K-tile DMA the counted waits count
     static_assert(MJV_GELU_NEG_OFF % 8 == 0 && MJV_GELU_NEG_OFF / 8 <= 8 * 64, "eight 64-lane instructions cover a table half");
@@ -924,12 +923,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       // GELU by table, a whole column group (8 fragments = 32 elements per lane) at a time: the indices of all 32 first, ONE
       // wave-wide range test, then 32 LDS gathers in flight together.  Fragment by fragment (round 2, first form) every
       // quad of gathers was followed by its own s_waitcnt lgkmcnt(0) and its own wave vote: 32 exposed LDS latencies per lane.
-      // Fast path = every element of every lane of the wave inside the table (|x| in [2^-23, 5.56): all but one activation
-      // in ~10^7 for unit-scale inputs): magnitude - LO + sign * R indexes the table directly; otherwise the general form
-      // (x/2 below the table, x or -0 above).
       // (round 4) the gather address is the rounded value's own bit pattern: (bits >> 15) - 2 LO = 65536 sign + 2 (|x| bits - LO).
-      // Fast path = every element of every lane of the wave inside the table, decided from the running min / max of |x| (the
-      // magnitudes' order is the patterns' order); otherwise the general form (x / 2 below the table, x or -0 above).
+      // Fast path = every element of every lane of the wave inside the table (|x| in [2^-23, 128): the table runs far past 5.56,
+      // where GELU becomes x / -0, because a trained ViT has some |x| > 5.56 in nearly every 2048-element vote), decided from the
+      // running min / max of |x| (the magnitudes' order is the patterns' order); otherwise the general form (x / 2 below the
+      // table, x or -0 above).
       unsigned ubs[8][4];
       float amax = 0.f, amin = __uint_as_float(0x7f000000u);
 #pragma unroll
