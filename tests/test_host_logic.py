@@ -529,3 +529,26 @@ def test_scoring_entry_points_refuse_the_bench_library(monkeypatch):
     monkeypatch.setattr(_lib, "is_bench_build", lambda: True)
     with pytest.raises(_lib.MjvLibraryError, match="bench build"):
         _lib.assert_product_library()
+
+
+def test_committed_gelu_table_equals_torch_for_every_bf16_input():
+    """mj-video_amd/csrc/gelu_table.h (generated, committed) restated on the CPU: |x| bits < LO -> x / 2, >= HI -> x / -0, else the
+    table - equal to torch's bf16 GELU (erf form: F.gelu on the bf16 Linear output, modeling_intern_vit.py:259-261) for every
+    finite bf16 input whose half is normal.  The GPU suite checks the KERNELS on every input; this pins the table itself, and the
+    window the GEMM epilogue's fast path relies on (2^-23 <= |x| < 128: real activations stay inside it)."""
+    import re
+    src = open(os.path.join(ROOT, "mj-video_amd", "csrc", "gelu_table.h")).read()
+    val = lambda name: int(re.search(rf"#define {name} (\S+)", src).group(1), 0)   # noqa: E731
+    LO, HI, R, NEG, LEN = val("MJV_GELU_LO"), val("MJV_GELU_HI"), val("MJV_GELU_R"), val("MJV_GELU_NEG_OFF"), val("MJV_GELU_TABLE_LEN")
+    body = src[src.index("MJV_GELU_TABLE_INIT {"):]
+    tab = np.array([int(t, 16) for t in re.findall(r"0x[0-9a-f]{4}", body)], dtype=np.int64)
+    assert len(tab) == LEN and R == HI - LO and NEG >= R and NEG % 8 == 0 and LEN >= NEG + R and LEN % 8 == 0
+    assert LO <= 0x3400 and HI >= 0x4300, "the fast path's window: 2^-23 <= |x| < 128"
+    bits = np.arange(65536, dtype=np.int64)
+    x = torch.from_numpy(bits.astype(np.uint16).view(np.int16)).view(torch.bfloat16)
+    want = torch.nn.functional.gelu(x).view(torch.int16).numpy().astype(np.int64) & 0xFFFF
+    half = (x.float() * 0.5).to(torch.bfloat16).view(torch.int16).numpy().astype(np.int64) & 0xFFFF
+    mag, sign = bits & 0x7FFF, bits >> 15
+    got = np.where(mag < LO, half, np.where(mag >= HI, np.where(sign == 1, 0x8000, bits), tab[np.clip(mag - LO, 0, R - 1) + sign * NEG]))
+    check = (mag >= 0x0100) & (mag < 0x7F00)      # finite inputs whose half is a normal number (as tools/gen_gelu_table.py)
+    assert np.array_equal(got[check], want[check]), int((got[check] != want[check]).sum())
