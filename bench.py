@@ -19,7 +19,11 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   "cpu_baseline": the oracle (CPU restatement of the reference forward, bf16, LM head included as the
                   reference executes it) timed on this host: 1 warm-up + 2 timed forwards of ONE video, for the C2
                   (headline) and the C1 (224^2) shapes, CPU model / physical cores / threads stated (N=1 only),
-  "latency":      one video per forward (the reference's real call pattern, eval_genai_mjvideo.py:140-141), ms.
+  "latency":      one video per forward (the reference's real call pattern, eval_genai_mjvideo.py:140-141), ms,
+  "secondary":    (N=1 default run only) the BASELINE.json configs this command line is not quoted on, measured in the same
+                  process AFTER the headline's timed region and never mixed into `value`: `fp8_ffn` (configs[4]'s weight path
+                  on the 2B stand-in), `pairs8` (configs[2]'s per-GPU shard: the weak-scaling baseline at N = 1),
+                  `c4_112_tiles` (configs[3]).  A failing leg reports its error and leaves the headline alone.
 """
 import argparse
 import json
@@ -111,6 +115,113 @@ def cpu_baseline(image_size, n_tiles, threads, iters=2):
 
 METRIC = "video-pairs scored/sec, MJ-VIDEO-2B 8-frame bf16, 1/2/4/8 MI355X"   # BASELINE.json "metric", verbatim
 
+# SURVEY.md Appendix A, per video at C2: the five FFN Linears = fc1 + fc2 (2 x 1650.9 GF) + w1|w3 (3512.7) + w2 (1756.4)
+FFN_TFLOP_PER_PAIR = 2 * (2 * 1650.9 + 3512.7 + 1756.4) / 1e3          # 17.14 of the 25.8 TFLOP per pair
+ALGO_TFLOP_PER_PAIR_C4 = 2 * 250.6                                      # 250.6 TFLOP per 112-tile video
+
+
+def synthetic_batch(cfg, dev, pairs, S, F, seed):
+    """``pairs`` pairs of synthetic videos of ``F`` tiles @``S``^2, resident in HBM: (pixel_values, input_ids, mask, N)"""
+    per_tile = num_image_tokens_per_tile(cfg)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    px = torch.randn(2 * pairs * F, 3, S, S, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    rows = []
+    for p in range(pairs):
+        row = synth.synth_input_ids(per_tile * F, caption_seed=seed * 1000 + p)
+        rows += [row, row]
+    ids, mask = synth.pad_batch(rows)
+    return px, ids.to(dev), mask.to(dev), int(ids.shape[1])
+
+
+def time_forwards(model, px, ids, mask, pairs, steps, warmup, profile=False):
+    """``warmup`` untimed + ``steps`` timed forwards of one batch (fresh id / mask tensors each, as the headline does).  With
+    ``profile`` the LAST warm-up forward carries HIP events around every kernel launch (its per-kernel table is returned)."""
+    def one():
+        model.forward(px, ids.clone(), mask.clone())
+        return model.last_packed34
+    res = None
+    for w in range(warmup):
+        if profile and w == warmup - 1:
+            torch.cuda.synchronize()
+            ops.prof_filter(None); ops.prof_reset(); ops.prof_enable(True)
+            one()
+            torch.cuda.synchronize()
+            ops.prof_enable(False)
+            res = ops.prof_results()
+            ops.prof_reset()
+        else:
+            one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if not torch.isfinite(out).all():
+        raise RuntimeError("non-finite scores")
+    return {"value": round(pairs * steps / dt, 4), "unit": "pairs/s", "ms_per_step": round(1e3 * dt / steps, 3),
+            "steps": steps, "warmup": warmup, "pairs_per_step": pairs}, res
+
+
+def secondary_legs(model, cfg, dev, px, ids, mask, seq_len):
+    """The configs the default command line is not quoted on (module docstring "secondary"), each in its own try block."""
+    sec = {}
+
+    def leg(name, fn):
+        t0 = time.perf_counter()
+        try:
+            sec[name] = fn()
+        except Exception as e:   # a secondary leg never costs the headline
+            sec[name] = {"value": None, "error": repr(e)}
+        sec[name]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+
+    def fp8_ffn():
+        model.set_ffn_format("mxfp8")
+        try:
+            r, res = time_forwards(model, px, ids, mask, pairs=4, steps=10, warmup=3, profile=True)
+        finally:
+            model.set_ffn_format("bf16")
+        f8 = {k: v for k, v in res.items() if k.startswith("gemm256f8") and v["ms"] > 0}
+        name, k = max(f8.items(), key=lambda kv: kv[1]["ms"])
+        tfl = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        ceiling = 1.0 / (FFN_TFLOP_PER_PAIR / MFMA_FP8_PEAK_TFLOPS + (ALGO_TFLOP_PER_PAIR - FFN_TFLOP_PER_PAIR) / MFMA_BF16_PEAK_TFLOPS)
+        r.update({
+            "baseline_config": "configs[4]'s fp8 MFMA weight path on the 2B stand-in (no 4B reference exists); same batch as the headline",
+            "dtype": "fp8-e4m3 (MXFP8, block-32 e8m0 scales) operands + fp32 accumulate in the five FFN GEMMs of both towers, bf16 elsewhere",
+            "roofline": {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tfl / MFMA_FP8_PEAK_TFLOPS, 4), "launches": k["launches"],
+                         "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4)},
+            "mixed_roofline": {"ceiling_pairs_per_s": round(ceiling, 2), "frac": round(r["value"] / ceiling, 4),
+                               "note": f"{FFN_TFLOP_PER_PAIR:.2f} TFLOP of FFN per pair at the 5 PFLOP/s fp8 peak + "
+                                       f"{ALGO_TFLOP_PER_PAIR - FFN_TFLOP_PER_PAIR:.2f} TFLOP at the 2.5 PFLOP/s bf16 peak"},
+            "fp8_kernels": {n: {"ms_per_step": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                            for n, v in sorted(f8.items(), key=lambda kv: -kv[1]["ms"])}})
+        return r
+
+    def pairs8():
+        px8, ids8, mask8, n8 = synthetic_batch(cfg, dev, 8, 448, 8, seed=7)
+        r, _ = time_forwards(model, px8, ids8, mask8, pairs=8, steps=5, warmup=1)
+        r.update({"baseline_config": "configs[2]'s per-GPU shard (8 pairs = 16 videos per GPU per step) on ONE GPU: the N = 1 point "
+                                     "a weak-scaling efficiency of `--gpus N` (8 pairs per GPU) divides by",
+                  "dtype": "bf16", "N": n8, "frac_of_mfma_roofline": round(r["value"] * ALGO_TFLOP_PER_PAIR / MFMA_BF16_PEAK_TFLOPS, 4)})
+        return r
+
+    def c4():
+        px4, ids4, mask4, n4 = synthetic_batch(cfg, dev, 1, 448, 112, seed=9)
+        r, _ = time_forwards(model, px4, ids4, mask4, pairs=1, steps=2, warmup=1)
+        ceiling = MFMA_BF16_PEAK_TFLOPS / ALGO_TFLOP_PER_PAIR_C4
+        r.update({"baseline_config": "configs[3]: 16 frames x 7 dynamic tiles = 112 tiles per video (long-context image tokens), "
+                                     "one pair = 2 videos per step",
+                  "dtype": "bf16", "N": n4, "roofline_pairs_per_s": round(ceiling, 3),
+                  "frac_of_mfma_roofline": round(r["value"] / ceiling, 4)})
+        return r
+
+    leg("fp8_ffn", fp8_ffn)
+    leg("pairs8", pairs8)
+    leg("c4_112_tiles", c4)
+    torch.cuda.empty_cache()
+    return sec
+
 
 def dp_step(score_local, global_pairs, device):
     """One step of the benchmark at any N: the batch's pairs are sharded over the ranks by ``parallel.score_pairs_dp`` (the
@@ -152,6 +263,8 @@ def main():
                     help="skip the single-video latency section (profiling runs: keeps small-batch launches out of the "
                          "per-kernel statistics)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` legs (fp8 FFN path, the 8-pair shard, the 112-tile config) of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4]'s weight path on the 2B stand-in: the five FFN Linears of both towers on MXFP8 (e4m3, "
                          "block-32 e8m0 scales) operands, fp32 accumulate (model.set_ffn_format('mxfp8')).  Its own line, its own "
@@ -266,7 +379,12 @@ def main():
         raise SystemExit("non-finite scores")
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     ranks_seen = 1
+    rank_ms = [1e3 * elapsed / args.steps]
     if use_dist:
+        # every rank's own clock over the timed region (a straggler shows as max >> min), then the contract's MAX over ranks
+        every = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, t)
+        rank_ms = [1e3 * float(x) / args.steps for x in every.tolist()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         who = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(who, torch.tensor([rank], dtype=torch.int64, device=dev))   # RCCL all-gather
@@ -283,7 +401,10 @@ def main():
             "vs_baseline": None,
             "dtype": ("fp8-e4m3 (MXFP8, block-32 e8m0 scales) operands + fp32 accumulate in the FFN GEMMs, bf16 elsewhere"
                       if args.fp8 else "bf16"),
-            "data": "synthetic", "ranks_seen": ranks_seen, "norm_fusion": bool(model.norm_fusion),
+            "data": "synthetic", "ranks_seen": ranks_seen,
+            "ms_per_step_by_rank": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
+                                    "all": [round(x, 3) for x in rank_ms]},
+            "norm_fusion": bool(model.norm_fusion),
             "attention_scores": model.attention_scores,
             "process_group": ("nccl" if use_dist else None),
             "config": {"workload": (f"MJ-VIDEO-2B, batch={args.pairs * world} pairs"
@@ -364,6 +485,9 @@ def main():
             line["latency"] = {"one_video_per_forward_ms": round(lat_ms, 3), "host_enqueue_ms": round(host_ms, 3),
                                "pairs_per_s_at_batch_1_video": round(0.5e3 / lat_ms, 3),
                                "note": "back-to-back single-video forwards, not part of `value`"}
+        if (world == 1 and not use_dist and not args.no_secondary and not args.fp8 and (S, F, args.pairs) == (448, 8, 4)
+                and not os.environ.get("MJV_BENCH_NORM_FUSION") and not args.gemm_code):
+            line["secondary"] = secondary_legs(model, cfg, dev, px, ids, mask, seq_len)
         if world == 1 and not args.no_cpu_baseline and not args.fp8:
             # oneDNN bf16 GEMMs stop scaling (and oversubscribe NUMA domains) far below a 256-thread host: cap at 32
             cpu_model, phys, logical = host_cpu_info()

@@ -18,7 +18,11 @@
  *     different threads on different streams do not interact; the only shared state is the opt-in profiler (mutex);
  *     the measurement switches of earlier ABI versions live in the separate bench build (include/mjv_bench.h);
  *   - return value 0 = ok, negative = error (MJV_E_*); `mjv_last_error()` gives a thread-local message.
- *   - rounding points follow the reference's bf16 eager path (bf16 result after every torch op).
+ *   - rounding points follow the reference's bf16 eager path (bf16 result after every torch op), with ONE stated exception:
+ *     attention's score_round_mode 2 keeps the scores in fp32 up to the softmax, as the reference's flash-attention path does
+ *     on a GPU (modeling_intern_vit.py:229-244, modeling_internlm2.py:437-561).  Modes 0 / 1 are the eager rounding points;
+ *     the Python model's DEFAULT is mode 2 (model.attention_scores = "flash"; "eager" selects 0 / 1; DESIGN 4 "Attention,
+ *     round 4" holds the fixtures' verdict on the two).
  *
  * ABI 5 adds the MX-fp8 operand format for the GEMMs (BASELINE configs[4]; opt-in, the default path
  * is bf16 as before): the `*_format` / `*_scales` fields at the END of the GEMM descriptor - all zero = bf16 everywhere -,
@@ -157,6 +161,8 @@ int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream);
  *   non-causal D=64 : internvl2/modeling_intern_vit.py:210-227 (_naive_attn) / :229-244 (_flash_attn)
  *   causal GQA D=128: internvl2/modeling_internlm2.py:383-411 (eager) / :437-561 (flash varlen)
  * Q/K/V/O are addressed as base + row * ld + head * head_stride (elements); K/V head = q_head / kv_group.
+ * Alignment: Q, K, V, O 16-byte aligned; ldq / ldk / ldv / ldo and the four head strides multiples of 8 elements (every
+ * kernel moves 16-byte pieces of a row; O included since round 4).
  * score rounding: mode 0: s = bf16(acc * scale)   [(q*scale) @ k^T with scale a power of two]
  *                 mode 1: s = bf16(bf16(acc) * scale)   [matmul, then / sqrt(D) in bf16]
  *                 mode 2: s = acc * scale in fp32, never rounded   [the reference's flash-attention numerics, the path it takes on
@@ -177,9 +183,10 @@ typedef struct mjv_attn_desc {
   int32_t kernel;             /* 0 = automatic (round 3: the two-sub-block pipelined kernel); 4 = the register-staged round-1
                                  kernel for every shape;
                                  5 = the round-2 choice (its LDS-DMA form up to 4096 keys); 6 / 7 = the round-3 kernel with two /
-                                 four waves (128 / 256 queries at head_dim 64, 64 / 128 at 128) per workgroup (automatic = four;
-                                 bit-identical results).  Every choice gives correct results: the tests A/B them.  Other
-                                 values: MJV_E_ARG */
+                                 four waves (128 / 256 queries at head_dim 64; 128 at 128) per workgroup (automatic = four;
+                                 bit-identical results).  6 exists at head_dim 64 only: at 128 a workgroup stages 64 KiB of
+                                 K / V, two fit a CU, and a two-wave block would run one wave per SIMD - MJV_E_UNSUPPORTED.
+                                 Every accepted choice gives correct results: the tests A/B them.  Other values: MJV_E_ARG */
 } mjv_attn_desc;
 
 int mjv_attention_bf16(const mjv_attn_desc* d, void* stream);

@@ -164,11 +164,16 @@ def is_bench_build() -> bool:
 
 
 def assert_product_library() -> None:
-    """Scoring entry points (scripts/eval/*, the harness) call this: an inherited MJV_LIBRARY must not silently swap the bench
-    build - process-wide switches, variants that skip work - under an evaluation."""
-    if is_bench_build():
-        raise MjvLibraryError("the bench build of the library (libmjv_hip_bench.so, MJV_LIBRARY) is loaded: it carries process-wide "
-                              "measurement switches and must not score; unset MJV_LIBRARY")
+    """Scoring entry points call this (scripts/eval/* mains, ``harness.score_pair_batch`` / ``score_collated_batch`` /
+    ``evaluate_*``): an inherited MJV_LIBRARY must not silently swap a diagnostics build under an evaluation.
+    Refused: the bench build (process-wide measurement switches, variants that skip work) AND any library loaded from a path
+    other than the in-tree product library - the stamps build exports no bench symbol and would pass a symbol test.
+    Direct ``model.forward`` calls (tools/, tests A/B-ing builds) are not policed: they choose their library on purpose."""
+    load_library()
+    path = os.path.realpath(os.environ.get("MJV_LIBRARY") or LIB_PATH)
+    if is_bench_build() or path != os.path.realpath(LIB_PATH):
+        raise MjvLibraryError(f"a diagnostics build of the library is loaded ({path}; MJV_LIBRARY): bench / stamps builds carry "
+                              "measurement switches or instrumentation and must not score; unset MJV_LIBRARY")
 
 
 def check(rc: int, what: str) -> None:

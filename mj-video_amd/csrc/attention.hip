@@ -1132,9 +1132,21 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
     // launch size where the smaller block could pay - ONE video per forward, 144 causal blocks of 256 queries on 256 CUs:
     // 1.43 ms of causal attention per video with two waves against 1.28 ms with four (tools/single_video_profile.py); every
     // block stages all its keys, so halving the block doubles the staging per query
+    // D = 128 has no two-wave form: a block stages 64 KiB of K / V whatever its wave count, so the CU holds two blocks and a
+    // two-wave block would leave ONE wave per SIMD (the compiler said so for every such instantiation: "desired occupancy was
+    // 2, final occupancy is 1") - refused instead of run at half occupancy
     const bool small = kernel == 6;
-    if (small) go(std::integral_constant<int, 2>{});
-    else go(std::integral_constant<int, 4>{});
+    if constexpr (D == 128) {
+      if (small) {
+        mjv_set_error("attention: kernel 6 (two waves per workgroup) exists for head_dim 64 only - at head_dim 128 the 64 KiB of "
+                      "staged K / V per workgroup would leave one wave per SIMD; use kernel 0 / 7");
+        return MJV_E_UNSUPPORTED;
+      }
+      go(std::integral_constant<int, 4>{});
+    } else {
+      if (small) go(std::integral_constant<int, 2>{});
+      else go(std::integral_constant<int, 4>{});
+    }
     return mjv_check_launch("attention");
   }
   // LDS-DMA staging up to 4096 keys per sequence (measured +2 ... +3 % at 1025 / 2186, 0 at 2048 non-causal); beyond that
@@ -1183,11 +1195,13 @@ extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
               "attention: score_round_mode 2 (unrounded fp32 scores) exists in the round-3 kernel only (kernel 0, 6 or 7)");
   MJV_REQUIRE(d->n_seqs > 0 && d->max_seqlen > 0 && d->n_heads > 0 && d->kv_group > 0, "attention: bad sizes");
   MJV_REQUIRE(d->n_heads % d->kv_group == 0, "attention: n_heads %% kv_group != 0");
-  MJV_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "attention: ld alignment");
+  // (O: the round-3 kernel writes 16-byte pieces of a row - kernels 0 / 6 / 7; the older kernels' 8-byte stores are held to the
+  // same contract so that one sentence in mjv.h covers every choice)
+  MJV_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 8 == 0, "attention: ld alignment (multiples of 8 elements)");
   MJV_REQUIRE(d->q_head_stride % 8 == 0 && d->k_head_stride % 8 == 0 && d->v_head_stride % 8 == 0 &&
-                  d->o_head_stride % 4 == 0, "attention: head stride alignment");
-  MJV_REQUIRE(((uintptr_t)d->Q | (uintptr_t)d->K | (uintptr_t)d->V) % 16 == 0 && (uintptr_t)d->O % 8 == 0,
-              "attention: misaligned pointer");
+                  d->o_head_stride % 8 == 0, "attention: head stride alignment (multiples of 8 elements)");
+  MJV_REQUIRE(((uintptr_t)d->Q | (uintptr_t)d->K | (uintptr_t)d->V | (uintptr_t)d->O) % 16 == 0,
+              "attention: misaligned pointer (Q, K, V, O must be 16-byte aligned)");
   // K / V staging offsets inside one sequence are 32-bit byte offsets (row * ld * 2)
   MJV_REQUIRE((double)d->max_seqlen * (double)(d->ldk > d->ldv ? d->ldk : d->ldv) * 2.0 < 2147483648.0,
               "attention: max_seqlen * max(ldk, ldv) * 2 = %.0f bytes does not fit the 32-bit staging offsets",

@@ -46,7 +46,7 @@ MJV_DEV float gelu_lut(float xf, const u16* tab) {
   const bool in_tab = rel < (unsigned)MJV_GELU_R;
   const unsigned idx = in_tab ? rel + (sgn & MJV_GELU_NEG_OFF) : 0u;
   const unsigned t = tab[idx];
-  const unsigned big = sgn ? 0x80000000u : u;                   // beyond the table: x for x > 0, -0 for x < 0
+  const unsigned big = gelu_beyond_table(u, mag);               // beyond the table (mjv_common.h)
   const unsigned small = __float_as_uint(0.5f * xf);            // below the table: x / 2
   const unsigned other = mag < MJV_GELU_LO ? small : big;
   return __uint_as_float(in_tab ? (t << 16) : other);
@@ -556,7 +556,7 @@ MJV_DEV float gelu_lut_split(float xf, const char* lds) {
   const unsigned sgn = (unsigned)((int)u >> 31);
   const bool in_tab = rel < (unsigned)MJV_GELU_R;
   const unsigned t = *(const u16*)(lds + (sgn & G_NEG) + (in_tab ? rel * 2 : 0u));
-  const unsigned big = sgn ? 0x80000000u : u;
+  const unsigned big = gelu_beyond_table(u, mag);               // beyond the table (mjv_common.h)
   const unsigned small = __float_as_uint(0.5f * xf);
   const unsigned other = mag < MJV_GELU_LO ? small : big;
   return __uint_as_float(in_tab ? (t << 16) : other);
@@ -936,8 +936,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         for (int r = 0; r < 4; ++r) {
           const float xr = rbf(lin(i, j, r));
           ubs[i][r] = __float_as_uint(xr);
-          amax = fmaxf(amax, fabsf(xr));
-          amin = fminf(amin, fabsf(xr));
+          // IEEE-754-2019 maximum / minimum (v_maximum3_f32 / v_minimum3_f32 on gfx950): a NaN operand makes the result NaN, so
+          // a NaN pre-activation fails both range tests below and the vote takes the general form, which propagates it
+          // (fmaxf / fminf DROP a NaN operand: ADVICE r4)
+          amax = __builtin_elementwise_maximum(amax, fabsf(xr));
+          amin = __builtin_elementwise_minimum(amin, fabsf(xr));
         }
       const bool all_in = amin >= __uint_as_float((unsigned)MJV_GELU_LO << 16) && amax < __uint_as_float((unsigned)MJV_GELU_HI << 16);
       if (__all(all_in)) {
@@ -1743,7 +1746,8 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   g_num_cus = mjv_device_cus();   // tail peeling and split-K plan against the CUs of THIS device (partitioned parts differ)
   const double flops = 2.0 * d->M * (double)d->N * d->K;
-  const double bytes = 2.0 * ((double)d->M * d->K + (double)d->N * d->K + (double)d->M * d->N);
+  // (algorithmic bytes: A and W read once, the output written once - N / 2 columns for the SiLU-mul epilogue)
+  const double bytes = 2.0 * ((double)d->M * d->K + (double)d->N * d->K + (double)d->M * (d->epilogue == MJV_EPI_SILU_MUL ? d->N / 2 : d->N));
   // Wave quantisation: with one 256x256 workgroup per CU a launch runs in ceil(tiles / 256) rounds, and a last round
   // that is mostly empty costs a full tile time (M = 17488, N = 2048: 552 tiles = 2.16 rounds -> 3).  When the last
   // round is under-filled, the trailing m-tile rows are peeled off and run as 128x128 tiles (2 workgroups per CU,

@@ -61,7 +61,7 @@ MJV_DEV float gelu_lut(float xf, const u16* tab) {
   const bool in_tab = rel < (unsigned)MJV_GELU_R;
   const unsigned idx = in_tab ? rel + (sgn & MJV_GELU_NEG_OFF) : 0u;
   const unsigned t = tab[idx];
-  const unsigned big = sgn ? 0x80000000u : u;
+  const unsigned big = gelu_beyond_table(u, mag);               // beyond the table (mjv_common.h)
   const unsigned small = __float_as_uint(0.5f * xf);
   const unsigned other = mag < MJV_GELU_LO ? small : big;
   return __uint_as_float(in_tab ? (t << 16) : other);

@@ -33,6 +33,16 @@ MJV_DEV float rbf(float f) {
 }
 MJV_DEV unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
+// GELU of a bf16 value whose magnitude lies past the table (|x| >= 128), as torch's CPU bf16 kernel returns it (x * 0.5 * (1 + erf)
+// in fp32, rounded): x for finite x > 0 until 2 x overflows fp32 (bf16 patterns 0x7f00..0x7f7f -> +inf), -0 for finite x < 0, NaN
+// for +-inf (inf * 0), a NaN operand quieted with its payload kept.  u = the value's fp32 bits, mag = (u >> 16) & 0x7fff.
+MJV_DEV unsigned gelu_beyond_table(unsigned u, unsigned mag) {
+  const bool neg = (int)u < 0;
+  const unsigned finite = neg ? 0x80000000u : (mag >= 0x7f00u ? 0x7f800000u : u);
+  const unsigned nonfinite = (u & 0x7fffffffu) == 0x7f800000u ? (neg ? 0x7fc00000u : 0xffc00000u) : (u | 0x00400000u);
+  return mag >= 0x7f80u ? nonfinite : finite;
+}
+
 MJV_DEV void unpack8(const u32x4& v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

@@ -14,6 +14,7 @@ from typing import Iterable, List, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import _lib
 from .chat_input import prepare_chat_input, video_prefix
 
 VOTE_TYPES = ("leftvote", "rightvote", "bothbad_vote", "tievote")
@@ -128,6 +129,7 @@ def prefetch_to_device(batches: Iterable, device, depth: int = 1):
 def score_pair_batch(model, config, tokenizer, examples: Sequence[dict], generation_config: dict) -> torch.Tensor:
     """examples: dicts with ``prompt``, ``left_pixels``, ``right_pixels`` (each [F,3,S,S] bf16).  Both videos of
     every pair go through ONE packed forward; returns ``[len(examples), 2, 1 + n_aspects + n_objectives]`` fp32."""
+    _lib.assert_product_library()   # an evaluation never scores on a diagnostics build of the kernels
     dev = model.model.device
     px, ids = [], []
     for ex in examples:
@@ -154,6 +156,7 @@ def score_collated_batch(model, batch: dict):
     ``video_{0,1}_input_ids [B, N]`` and ``video_{0,1}_attention_mask``.  The 5-D pixel block is flattened to
     ``[B*F, 3, H, W]`` exactly as the trainer does; both videos of every pair go through one packed forward.
     Returns ``(output_video_0, output_video_1)`` (CustomOutput each)."""
+    _lib.assert_product_library()
     dev = model.model.device
     outs = []
     px = [batch[f"video_{i}_pixel_values"] for i in (0, 1)]

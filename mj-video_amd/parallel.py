@@ -50,18 +50,22 @@ def score_pairs_dp(score_fn: Callable[[Sequence], torch.Tensor], pairs: Sequence
             local = score_fn(pairs[lo:hi]).float()
         except Exception as e:   # noqa: BLE001 - re-raised below, after the collective
             error = e
-    if local is not None:
-        device = local.device
-        if local.dim() != 3 or local.shape[1] != 2 or local.shape[-1] != width:
-            bad_width = tuple(local.shape)
-            local = None
+    # The block's device is derived the SAME way on every rank, before looking at what score_fn returned: the caller's
+    # `device`, else the backend's natural one (nccl: this rank's current GPU; gloo / others: the CPU).  A rank whose score_fn
+    # raised has no tensor to take a device from, and a guess that differs from the healthy ranks' would mix devices inside
+    # the all-gather - a failure or a hang exactly where the error is supposed to be reported.
     if device is None:
         if dist.get_backend(group) == "nccl" and torch.cuda.is_available():
             device = torch.device("cuda", torch.cuda.current_device())
-        elif error is not None:
-            device = torch.device("cpu")
         else:
-            raise ValueError("a rank with an empty shard needs `device` to build its (padding) block")
+            device = torch.device("cpu")
+    device = torch.device(device)
+    if local is not None:
+        if local.dim() != 3 or local.shape[1] != 2 or local.shape[-1] != width:
+            bad_width = tuple(local.shape)
+            local = None
+        else:
+            local = local.to(device)
     # one trailing status row per block: [0, 0] = 0 ok / 1 wrong block shape / 2 score_fn raised
     block = torch.zeros(per + 1, 2, width, dtype=torch.float32, device=device)
     if local is not None:

@@ -116,9 +116,10 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-@pytest.mark.parametrize("scores,fused", [("flash", True), ("eager", False)])
+@pytest.mark.parametrize("scores,fused", [("flash", False), ("flash", True), ("eager", False)])
 def test_tiny_cases_against_golden(cuda, scores, fused):
-    """(both of the reference's attention numerics - model.attention_scores - against the same reference-executed fixtures)"""
+    """(the shipped default - flash scores, norms not folded - first; then both of the reference's attention numerics -
+    model.attention_scores - and the folded norms against the same reference-executed fixtures)"""
     from mj_video_amd import synth
     npz, meta = load_golden("tiny")
     names = [c["name"] for c in meta["cases"]]
@@ -574,7 +575,7 @@ def test_single_layer_at_production_shape(cuda, name, scores, fused):
     from util import apply_test_overrides
     model = apply_test_overrides(model.to(torch.bfloat16).to(cuda).eval())
     model.attention_scores = scores     # both of the reference's attention numerics are held to the same bound
-    model.norm_fusion = fused           # ... and the norms folded into their GEMMs (default) as well as the reference's rounding points
+    model.norm_fusion = fused           # ... and the norms folded into their GEMMs (opt-in) as well as the reference's rounding points (default)
     x = layer_input_rows(m["input_seed"], case["input_tag"], tuple(case["shape"]))
     y = (model.run_vit_layer(0, x) if case["tower"] == "vit" else model.run_llm_layer(0, x)).float().cpu()
     rows = npz[f"{name}/rows"]

@@ -527,8 +527,21 @@ def test_scoring_entry_points_refuse_the_bench_library(monkeypatch):
     assert not _lib.is_bench_build()
     _lib.assert_product_library()
     monkeypatch.setattr(_lib, "is_bench_build", lambda: True)
-    with pytest.raises(_lib.MjvLibraryError, match="bench build"):
+    with pytest.raises(_lib.MjvLibraryError, match="diagnostics build"):
         _lib.assert_product_library()
+    # a library from any other path is refused too (the stamps build exports no bench symbol: ADVICE r4)
+    monkeypatch.setattr(_lib, "is_bench_build", lambda: False)
+    monkeypatch.setenv("MJV_LIBRARY", os.path.join(os.path.dirname(_lib.LIB_PATH), "libmjv_hip_stamps.so"))
+    with pytest.raises(_lib.MjvLibraryError, match="diagnostics build"):
+        _lib.assert_product_library()
+    monkeypatch.delenv("MJV_LIBRARY")
+    _lib.assert_product_library()
+    # ... and the harness entry points call it before they touch the model
+    monkeypatch.setattr(_lib, "is_bench_build", lambda: True)
+    with pytest.raises(_lib.MjvLibraryError, match="diagnostics build"):
+        harness.score_pair_batch(None, None, None, [], {})
+    with pytest.raises(_lib.MjvLibraryError, match="diagnostics build"):
+        harness.score_collated_batch(None, {})
 
 
 def test_committed_gelu_table_equals_torch_for_every_bf16_input():
@@ -549,6 +562,9 @@ def test_committed_gelu_table_equals_torch_for_every_bf16_input():
     want = torch.nn.functional.gelu(x).view(torch.int16).numpy().astype(np.int64) & 0xFFFF
     half = (x.float() * 0.5).to(torch.bfloat16).view(torch.int16).numpy().astype(np.int64) & 0xFFFF
     mag, sign = bits & 0x7FFF, bits >> 15
-    got = np.where(mag < LO, half, np.where(mag >= HI, np.where(sign == 1, 0x8000, bits), tab[np.clip(mag - LO, 0, R - 1) + sign * NEG]))
-    check = (mag >= 0x0100) & (mag < 0x7F00)      # finite inputs whose half is a normal number (as tools/gen_gelu_table.py)
+    # beyond the table (mjv_common.h gelu_beyond_table): x, +inf once 2 x overflows fp32, -0 for finite x < 0, NaN for +-inf, NaN kept
+    beyond = np.where(mag >= 0x7F80, np.where(mag == 0x7F80, np.where(sign == 1, 0x7FC0, 0xFFC0), bits | 0x0040),
+                      np.where(sign == 1, 0x8000, np.where(mag >= 0x7F00, 0x7F80, bits)))
+    got = np.where(mag < LO, half, np.where(mag >= HI, beyond, tab[np.clip(mag - LO, 0, R - 1) + sign * NEG]))
+    check = mag >= 0x0100      # every input whose half is a normal number (as tools/gen_gelu_table.py) - infinities and NaNs included
     assert np.array_equal(got[check], want[check]), int((got[check] != want[check]).sum())

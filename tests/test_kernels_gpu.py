@@ -111,8 +111,36 @@ def test_gemm_gelu_is_exact_for_every_bf16_input(cuda, tile):
         # flushes subnormal results to 0, the table's x / 2 keeps them, and no activation gets there)
         same |= (got.float() == 0) & (ref.float() == 0)
         same |= a.float().abs() < 2.0 ** -125
-        same |= a.float().abs() >= 2.0 ** 127     # (torch forms x (1 + erf) before halving: inf from 2^127 on; the table returns x)
         assert same.all(), (order, int((~same).sum()), a[~same][:8], got[~same][:8], ref[~same][:8])
+
+
+def test_gemm_gelu_propagates_nonfinite_preactivations(cuda, tile):
+    """NaN / +-inf pre-activations (the fast path's wave-wide range test once ran on fmaxf / fminf, which DROP a NaN
+    operand, and gathered a finite value for it).  The values arrive through the BIAS (A = 0, so the sum is the bias exactly and a
+    non-finite value stays in its own column): one NaN / inf column among in-table columns - the vote must fail on the lanes that
+    hold it - then every non-finite bf16 pattern.  Must equal torch's CPU bf16 GELU: NaN where it gives NaN, bits elsewhere."""
+    from mj_video_amd import ops
+    M, N, K = 300, 64, 64
+    a = torch.zeros(M, K, dtype=BF, device=cuda)
+    w = rnd(N, K, seed=5).to(cuda)
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(BF)
+    nonfinite = bits[~torch.isfinite(bits.float())]          # 2 infinities + 508 NaN patterns
+    cases = []
+    for special in (float("nan"), float("inf"), -float("inf"), 3.0e38, -3.0e38):
+        for col in (0, 17, 63):
+            b = rnd(N, std=0.7, seed=col)
+            b[col] = special
+            cases.append(b)
+    pad = (-nonfinite.numel()) % N
+    cases += list(torch.cat([nonfinite, torch.ones(pad, dtype=BF)]).view(-1, N))
+    for b in cases:
+        out = torch.empty(M, N, dtype=BF, device=cuda)
+        ops.gemm(a, w, out, ops.EPI_BIAS_GELU, bias=b.to(cuda))
+        ref = F.gelu(b).expand(M, N)
+        got = out.cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)), (b, got[0], ref[0])
+        fin = ~torch.isnan(ref)
+        assert torch.equal(got[fin].view(torch.int16), ref[fin].view(torch.int16)), (b, got[0], ref[0])
 
 
 def test_gemm_scale_res_and_rowmaps(cuda, tile):
@@ -333,6 +361,19 @@ def attn_variant(request, cuda):
     ops.attention_set_variant(0)
 
 
+def two_wave_form_refused(cuda, variant, D):
+    """kernel 6 (two waves per workgroup) exists at head_dim 64 only (include/mjv.h): at 128 it would run one wave per SIMD and
+    is refused with MJV_E_UNSUPPORTED.  Returns True after checking the refusal, so the calling test ends there."""
+    if variant != 6 or D != 128:
+        return False
+    from mj_video_amd import ops, _lib
+    q = torch.zeros(64, D, dtype=BF, device=cuda)
+    cu = torch.tensor([0, 64], dtype=torch.int32, device=cuda)
+    with pytest.raises(_lib.MjvLibraryError, match="kernel 6"):
+        ops.attention(q, q, q, torch.empty_like(q), cu, 64, 1, 1, D, True, D ** -0.5, 1, kernel=6)
+    return True
+
+
 def attn_reference(q, k, v, lens, H, G, D, causal, scale, mode):
     """fp32 reference with the reference's score rounding; q [N, H*D], k/v [N, (H/G)*D] packed."""
     out = torch.zeros(q.shape[0], H * D)
@@ -365,6 +406,8 @@ def attn_reference(q, k, v, lens, H, G, D, causal, scale, mode):
 ])
 def test_attention(cuda, attn_variant, D, H, G, causal, lens):
     from mj_video_amd import ops
+    if two_wave_form_refused(cuda, attn_variant, D):
+        return
     N = sum(lens)
     KVH = H // G
     q, k, v = rnd(N, H * D, seed=1), rnd(N, KVH * D, seed=2), rnd(N, KVH * D, seed=3)
@@ -402,6 +445,8 @@ def test_attention_unrounded_scores_mode2(cuda, kernel, D, H, G, causal, lens):
     bounds as test_attention; and strictly closer to that reference than the eager-numerics result is (the rounding is really
     gone); the older kernels refuse the mode."""
     from mj_video_amd import ops, _lib
+    if two_wave_form_refused(cuda, kernel, D):
+        return
     N = sum(lens)
     KVH = H // G
     q, k, v = rnd(N, H * D, seed=1), rnd(N, KVH * D, seed=2), rnd(N, KVH * D, seed=3)
@@ -482,6 +527,8 @@ def test_attention_exact_selection(cuda, attn_variant):
     key<->value pairing of the transposed LDS reads and the causal/ragged masks"""
     from mj_video_amd import ops
     D, H, L = 128, 2, 200
+    if two_wave_form_refused(cuda, attn_variant, D):
+        return
     g = torch.Generator().manual_seed(3)
     v = torch.randn(L, D, generator=g).to(BF)
     target = torch.randint(0, L, (L,), generator=g)
@@ -661,7 +708,7 @@ def test_attention_dma_staging_race_screen(cuda):
         cu = torch.arange(0, (n_seq + 1) * L, L, dtype=torch.int32, device=cuda)
         outs = {}
         try:
-            for var in (4, 5, 5, 5, 0, 0, 0, 6, 7, 6, 7):
+            for var in (4, 5, 5, 5, 0, 0, 0, 6, 7, 6, 7) if D == 64 else (4, 5, 5, 5, 0, 0, 0, 7, 7):   # (6: head_dim 64 only)
                 ops.attention_set_variant(var)
                 with torch.cuda.stream(side):
                     ops.gemm(big_a, big_w, big_o, ops.EPI_BIAS)
@@ -674,7 +721,7 @@ def test_attention_dma_staging_race_screen(cuda):
         for i, o in enumerate(outs[5]):
             assert torch.equal(o, outs[4][0]), f"D={D} L={L} causal={causal}: DMA launch {i} differs from the register-staged kernel"
         # (a query's arithmetic does not depend on how many waves share its workgroup: two- and four-wave blocks agree bit for bit)
-        for i, o in enumerate(outs[0][1:] + outs[6] + outs[7]):
+        for i, o in enumerate(outs[0][1:] + outs.get(6, []) + outs[7]):
             assert torch.equal(o, outs[0][0]), f"D={D} L={L} causal={causal}: launch {i + 1} of the round-3 kernel differs from launch 0"
         rel = (outs[0][0].float() - outs[4][0].float()).norm() / outs[4][0].float().norm()
         assert rel.item() < 4e-3, f"D={D} L={L}: automatic kernel vs round-2 kernel relative L2 {rel.item():.2e}"
@@ -778,6 +825,8 @@ def test_attention_long_context_c4(cuda, attn_variant):
     chunks for the first/last/middle rows of two heads."""
     from mj_video_amd import ops
     D, H, G, L = 128, 2, 2, 28837
+    if two_wave_form_refused(cuda, attn_variant, D):
+        return
     q, k, v = rnd(L, H * D, seed=1), rnd(L, D, seed=2), rnd(L, D, seed=3)
     cu = torch.tensor([0, L], dtype=torch.int32)
     out = torch.empty(L, H * D, dtype=BF, device=cuda)
