@@ -216,6 +216,20 @@ def secondary_legs(model, cfg, dev, px, ids, mask, seq_len):
                   "frac_of_mfma_roofline": round(r["value"] / ceiling, 4)})
         return r
 
+    def prefix_cache_off():
+        keep = (model.prefix_cache, model.trim_last_layer)
+        model.prefix_cache = model.trim_last_layer = False
+        try:
+            r, _ = time_forwards(model, px, ids, mask, pairs=4, steps=10, warmup=2)
+        finally:
+            model.prefix_cache, model.trim_last_layer = keep
+        r.update({"baseline_config": "configs[1], the headline's batch, with model.prefix_cache = model.trim_last_layer = False: every "
+                                     "prompt row through all 24 decoder layers in every forward, every query in the last layer",
+                  "dtype": "bf16", "frac_of_mfma_roofline": round(r["value"] * ALGO_TFLOP_PER_PAIR / MFMA_BF16_PEAK_TFLOPS, 4)})
+        return r
+
+    if model.prefix_cache or model.trim_last_layer:
+        leg("prefix_cache_off", prefix_cache_off)
     leg("fp8_ffn", fp8_ffn)
     leg("pairs8", pairs8)
     leg("c4_112_tiles", c4)
@@ -263,6 +277,10 @@ def main():
                     help="skip the single-video latency section (profiling runs: keeps small-batch launches out of the "
                          "per-kernel statistics)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-prefix-cache", action="store_true",
+                    help="recompute the constant prompt prefix's rows in every forward and every query of the last decoder layer, as "
+                         "the reference does (model.prefix_cache = model.trim_last_layer = False); the default line states both "
+                         "switches in `config` and carries this setting as `secondary.prefix_cache_off`")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` legs (fp8 FFN path, the 8-pair shard, the 112-tile config) of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true",
@@ -312,6 +330,8 @@ def main():
     model.eval()
     if args.fp8:
         model.set_ffn_format("mxfp8")
+    if args.no_prefix_cache:
+        model.prefix_cache = model.trim_last_layer = False
     if os.environ.get("MJV_BENCH_NORM_FUSION"):   # A/B of DESIGN "Norm fusion, round 4" (never a reported headline: the line says so)
         model.norm_fusion = True
     for code in args.gemm_code:   # (bench build of the library only: MJV_LIBRARY=.../libmjv_hip_bench.so)
@@ -421,6 +441,12 @@ def main():
                                         "(configs[1]) and 8 at --gpus N > 1 (configs[2]): an efficiency against N = 1 needs "
                                         "`--gpus 1 --pairs 8` as its baseline"),
                        "ids": "fresh id / mask tensors every step (one device->host copy of the ids per forward)",
+                       # steady-state work removal a scorer is entitled to, STATED: the keys / values of the
+                       # constant prompt prefix (first 64 k tokens: system prompt + "Frame1: <img>") come from a cache filled by
+                       # the first forward, and the last decoder layer computes queries only from the first selected row on.
+                       # secondary.prefix_cache_off is the same workload with both off (every row, every forward)
+                       "prefix_cache": bool(model.prefix_cache), "prefix_cache_tokens": (model._prefix or {}).get("P", 0),
+                       "prefix_cache_hits": model.prefix_cache_hits, "trim_last_layer": bool(model.trim_last_layer),
                        "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
             "frac_of_mfma_roofline": round(value * ALGO_TFLOP_PER_PAIR / (MFMA_BF16_PEAK_TFLOPS * world), 4)
             if (S, F) == (448, 8) and not args.fp8 else None,

@@ -27,6 +27,9 @@
  * ABI 5 adds the MX-fp8 operand format for the GEMMs (BASELINE configs[4]; opt-in, the default path
  * is bf16 as before): the `*_format` / `*_scales` fields at the END of the GEMM descriptor - all zero = bf16 everywhere -,
  * mjv_quantize_mxfp8, mjv_layernorm_mxfp8, mjv_rmsnorm_mxfp8.
+ * ABI 6 adds, at the END of the attention descriptor (all zero = ABI 5): suffix queries (cu_seqlens_q) and a shared key / value
+ * prefix (prefix_k / prefix_v) for causal launches - the two pieces of work a scorer can leave out of the language tower - and
+ * lets MJV_EPI_ROPE_QKV run with rope_group 0 (a k | v projection without q heads).
  */
 #ifndef MJV_H_
 #define MJV_H_
@@ -37,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MJV_ABI_VERSION 5
+#define MJV_ABI_VERSION 6
 
 enum {
   MJV_OK = 0,
@@ -124,7 +127,7 @@ typedef struct mjv_gemm_desc {
   const int32_t* rope_pos;               /* [M] position of every row (device) */
   mjv_bf16 *rope_q, *rope_k;             /* outputs */
   int64_t rope_ldq, rope_ldk;
-  int32_t rope_group;                    /* q heads per kv head */
+  int32_t rope_group;                    /* q heads per kv head; 0 (ABI 6) = columns are [k | v] pairs only, rope_q unused */
   /* ---- ABI 5: operand / output formats (enum mjv_format; all zero = bf16 everywhere, the ABI-4 behaviour) ----
    * a_format == w_format == MJV_FMT_MXFP8: A and W point to e4m3 bytes (lda / ldw in BYTES = elements), a_scales / w_scales
    * to their scale records (layout above; groups = ceil(M / 64) and ceil(N / 64)); K % 128 == 0; the product of the
@@ -187,6 +190,20 @@ typedef struct mjv_attn_desc {
                                  bit-identical results).  6 exists at head_dim 64 only: at 128 a workgroup stages 64 KiB of
                                  K / V, two fit a CU, and a two-wave block would run one wave per SIMD - MJV_E_UNSUPPORTED.
                                  Every accepted choice gives correct results: the tests A/B them.  Other values: MJV_E_ARG */
+  /* ---- ABI 6 (all zero = the ABI-5 behaviour): what a SCORER may leave out of a causal tower (kernel 0 / 6 / 7, causal only;
+   * otherwise MJV_E_UNSUPPORTED).  The reward heads read two late rows per sample (moe_reward.py:226-243) and every prompt
+   * starts with the same system tokens (conversation.py:354-365, eval_genai_mjvideo.py:132-137):
+   *   cu_seqlens_q / max_seqlen_q : the queries of sequence s are only its LAST cu_seqlens_q[s+1] - cu_seqlens_q[s] positions,
+   *       packed at those rows of Q and O (cu_seqlens still describes the K / V rows); local query i sits at key position
+   *       prefix_len + keys(s) - queries(s) + i.  max_seqlen_q >= the longest query count.
+   *   prefix_k / prefix_v / prefix_len : prefix_len keys SHARED by every sequence precede its own: rows of prefix_k / prefix_v
+   *       [prefix_len][ldk / ldv] with K's / V's head strides (a cache of the constant prompt prefix's keys / values);
+   *       prefix_len % 64 == 0.  Key j < prefix_len comes from the prefix rows, key j >= prefix_len from row j - prefix_len
+   *       of the sequence.  Same arithmetic, same key-tile boundaries as one launch over the concatenated rows. */
+  const int32_t* cu_seqlens_q;
+  int32_t max_seqlen_q;
+  int32_t prefix_len;
+  const mjv_bf16 *prefix_k, *prefix_v;
 } mjv_attn_desc;
 
 int mjv_attention_bf16(const mjv_attn_desc* d, void* stream);

@@ -22,7 +22,7 @@ class MjvLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5  # MJV_ABI_VERSION of include/mjv.h
+ABI_VERSION = 6  # MJV_ABI_VERSION of include/mjv.h
 FMT_BF16, FMT_MXFP8 = 0, 1   # enum mjv_format
 
 
@@ -49,7 +49,10 @@ class AttnDesc(C.Structure):
                 ("o_head_stride", C.c_int32), ("cu_seqlens", C.c_void_p), ("n_seqs", C.c_int32),
                 ("max_seqlen", C.c_int32), ("n_heads", C.c_int32), ("kv_group", C.c_int32),
                 ("head_dim", C.c_int32), ("causal", C.c_int32), ("scale", C.c_float),
-                ("score_round_mode", C.c_int32), ("kernel", C.c_int32)]
+                ("score_round_mode", C.c_int32), ("kernel", C.c_int32),
+                # ABI 6 (zero = ABI 5): suffix queries, shared key / value prefix
+                ("cu_seqlens_q", C.c_void_p), ("max_seqlen_q", C.c_int32), ("prefix_len", C.c_int32),
+                ("prefix_k", C.c_void_p), ("prefix_v", C.c_void_p)]
 
 
 class HeadsDesc(C.Structure):

@@ -30,6 +30,13 @@ struct AttnArgs {
   float scale;
   int round_mode;
   int n_qb, n_seqs;   // q-blocks per sequence (of the launched kernel's block size), sequences
+  // ABI 6 (causal, attn2_kernel only): the queries of a sequence are the LAST rows of it (cu_q: their packed row offsets in
+  // Q / O; NULL = one query per key row, the same rows), and every sequence's keys are preceded by prefix_len SHARED keys
+  // (rows of Kp / Vp: same leading dimensions and head strides as K / V; prefix_len is a multiple of KB, so a key tile
+  // lies on one side of the boundary)
+  const int* cu_q;
+  const u16 *Kp, *Vp;
+  int prefix_len;
 };
 
 // Workgroup -> (sequence, head, q-block).  The grid is one-dimensional and hardware hands consecutive workgroup ids to
@@ -635,12 +642,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   if (!bid.valid) return;
   const int seq = bid.seq, head = bid.head;
   const int s0 = p.cu[seq];
-  const int len = p.cu[seq + 1] - s0;
+  const int len = p.cu[seq + 1] - s0;             // the sequence's own key rows
   const int kvh = head / p.kv_group;
+  // causal launches (ABI 6): P shared prefix keys in front of the own ones; the queries are the last lenq positions of the
+  // P + len keys, rows sq0 ... of Q / O.  Local query i sits at key position qsh + i.  (Non-causal: P = 0, queries = key rows.)
+  const int P = CAUSAL ? p.prefix_len : 0;
+  const int sq0 = (CAUSAL && p.cu_q) ? p.cu_q[seq] : s0;
+  const int lenq = (CAUSAL && p.cu_q) ? p.cu_q[seq + 1] - sq0 : len;
+  const int qsh = CAUSAL ? P + len - lenq : 0;
   // first-key-as-initial-state ("peel"): workgroup-uniform
   const bool peel = !CAUSAL && len > 1 && ((len - 1) % KB == 0);
-  const int klen = peel ? len - 1 : len;          // keys that go through the tiles (rows s0 + peel ...)
-  const int nq_main = peel ? len - 1 : len;       // queries of the ordinary blocks (queries peel ...)
+  const int klen = peel ? len - 1 : P + len;      // keys that go through the tiles (rows s0 + peel ...; prefix rows first)
+  const int nq_main = peel ? len - 1 : lenq;      // queries of the ordinary blocks (queries peel ...)
   const int nb_main = (nq_main + QBW - 1) / QBW;
   const int qb = CAUSAL ? nb_main - 1 - bid.qb : bid.qb;   // causal: heaviest blocks first
   if (CAUSAL ? (qb < 0) : (qb > nb_main || (qb == nb_main && !peel))) return;
@@ -652,7 +665,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   const int qw0 = cls_block ? 0 : (peel ? 1 : 0) + qb * QBW + wave * QW;
   // (query-0 block: waves 0 and 1 both hold the query and each takes one 32-key half of every tile - the state of wave 1 is
   // merged into wave 0's after the loop; a single wave walking all 1024 keys held the block's slot twice as long)
-  const int nq_wave = cls_block ? (wave < 2 ? 1 : 0) : max(0, min(QW, len - qw0));   // valid queries of this wave
+  const int nq_wave = cls_block ? (wave < 2 ? 1 : 0) : max(0, min(QW, lenq - qw0));   // valid queries of this wave
   const bool hasA = nq_wave > 0, hasB = NSUB == 2 && nq_wave > 32;
   int qi[NSUB];
   qi[0] = cls_block ? 0 : qw0 + l31;
@@ -665,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   bf16x8 qf[NSUB][F];
 #pragma unroll
   for (int sb = 0; sb < NSUB; ++sb) {
-    const int qr = s0 + (qi[sb] < len ? qi[sb] : len - 1);
+    const int qr = sq0 + (qi[sb] < lenq ? qi[sb] : lenq - 1);
     const u16* qp = p.Q + (long)qr * p.ldq + (long)head * p.qhs + 8 * hi;
 #pragma unroll
     for (int ks = 0; ks < F; ++ks) qf[sb][ks] = *(const bf16x8*)(qp + ks * 16);
@@ -688,8 +701,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 
   const u16* Kg = p.K + (long)kvh * p.khs;
   const u16* Vg = p.V + (long)kvh * p.vhs;
-  const char* const k_seq = (const char*)(Kg + (long)(s0 + (peel ? 1 : 0)) * p.ldk);   // key row 0 of the tiles
-  const char* const v_seq = (const char*)(Vg + (long)(s0 + (peel ? 1 : 0)) * p.ldv);
+  // (own rows: the base is shifted down by the P prefix rows, so a tile's row index kt * KB + row addresses prefix and own
+  // tiles alike - own tiles start at kt = P / KB and never reach below row s0)
+  const char* const k_seq = (const char*)(Kg + (long)(s0 + (peel ? 1 : 0) - P) * p.ldk);   // key row 0 of the tiles
+  const char* const v_seq = (const char*)(Vg + (long)(s0 + (peel ? 1 : 0) - P) * p.ldv);
+  const char* const kp_seq = P ? (const char*)(p.Kp + (long)kvh * p.khs) : k_seq;           // the shared prefix rows
+  const char* const vp_seq = P ? (const char*)(p.Vp + (long)kvh * p.vhs) : v_seq;
 
   if (peel && hasA && !(cls_block && wave == 1)) {
     // key 0 as the initial state.  s = q . k_0 in fp32 (this lane's 8-element groups, then the other half-lane's), rounded
@@ -735,8 +752,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     }
   }
 
-  const int q_last_w = qw0 + nq_wave - 1;                        // last valid query of this wave
-  const int kv_end = CAUSAL ? min(klen, qb * QBW + QBW) : klen;  // keys this workgroup needs
+  const int q_last_w = qsh + qw0 + nq_wave - 1;                  // key position of the last valid query of this wave
+  const int kv_end = CAUSAL ? min(klen, qsh + qb * QBW + QBW) : klen;  // keys this workgroup needs
   const int n_tiles = (kv_end + KB - 1) / KB;
 
   // ---- LDS-DMA staging (same image and swizzles as attn_kernel<.., DMA = true>), NW waves share a tile's 2 x CH instructions
@@ -781,7 +798,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
       gr = gr < klen ? gr : klen - 1;                   // rows past the end: any valid row (masked later)
       off = (unsigned)(gr * (int)(is_v ? p.ldv : p.ldk) + ((cl ^ sw) * 8)) * 2u;
     }
-    dma16(is_v ? v_seq : k_seq, off, lds0 + (unsigned)(boff + (is_v ? KBYTES : 0) + (j * NW + wave) * 1024));
+    const bool pre = CAUSAL && kt * KB < P;             // a tile of the shared prefix (whole by construction); wave-uniform
+    dma16(is_v ? (pre ? vp_seq : v_seq) : (pre ? kp_seq : k_seq), off, lds0 + (unsigned)(boff + (is_v ? KBYTES : 0) + (j * NW + wave) * 1024));
   };
   auto issue = [&](int kt, int boff) __attribute__((always_inline)) {
     if (kt * KB + KB <= klen) {
@@ -935,7 +953,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
       constexpr int u = decltype(uc)::value;
       constexpr int sb = (NSUB == 2) ? (u & 1) : 0, h = (NSUB == 2) ? (u >> 1) : u;
       const int kb = k0 + 32 * h;
-      const int q_last = qw0 + 32 * sb + min(31, nq_wave - 32 * sb - 1);   // last valid query of the sub-block
+      const int q_last = qsh + qw0 + 32 * sb + min(31, nq_wave - 32 * sb - 1);   // key position of the sub-block's last valid query
       if ((sb == 1 && !hasB) || kb >= klen || (CAUSAL && kb > q_last) || (cls_block && h != wave)) return;   // wave-uniform
       // every fragment of the unit is requested up front (K for the scores, V for the second product): read where they
       // are used, each product paid an LDS round trip per MFMA - 1 775 cycles for one unit in the query-0 block
@@ -952,12 +970,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < F; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[sb][ks], S, 0, 0, 0);
-      const int qmin = qw0 + 32 * sb;
+      const int qmin = qsh + qw0 + 32 * sb;
       if (kb + 32 > klen || (CAUSAL && kb + 31 > qmin)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= klen || (CAUSAL && key > qi[sb])) S[r] = -INFINITY;
+          if (key >= klen || (CAUSAL && key > qi[sb] + qsh)) S[r] = -INFINITY;
         }
       }
       unsigned pw[8];
@@ -1012,7 +1030,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     for (int g = 0; g < D / 32; ++g) vboff[g] ^= TB;
   };
   // leading tiles that are whole (all 64 keys exist) and need no mask for any query of this wave
-  const int n_whole = (!hasA || cls_block) ? 0 : min(n_tiles, CAUSAL ? max(0, (qw0 + 1) / KB) : klen / KB);
+  const int n_whole = (!hasA || cls_block) ? 0 : min(n_tiles, CAUSAL ? max(0, (qsh + qw0 + 1) / KB) : klen / KB);
   int kt = 0;
   if (NSUB == 2 && hasB) {
     if constexpr (NSUB == 2)
@@ -1063,10 +1081,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
   for (int sb = 0; sb < NSUB; ++sb) {
     const float l = xhalf_sum(lsum[sb]);
-    const bool ok = cls_block ? (wave == 0 && sb == 0 && l31 == 0) : (qi[sb] < len);   // (every wave of the query-0 block reaches this)
+    const bool ok = cls_block ? (wave == 0 && sb == 0 && l31 == 0) : (qi[sb] < lenq);   // (every wave of the query-0 block reaches this)
     if (!ok) continue;
     const float inv = 1.0f / l;
-    u16* op = p.O + (long)(s0 + qi[sb]) * p.ldo + (long)head * p.ohs;
+    u16* op = p.O + (long)(sq0 + qi[sb]) * p.ldo + (long)head * p.ohs;
     // 16-byte stores (round 4; cdna_hip_programming.md T21): the two half-lanes of a query hold alternating 4-element chunks
     // of its row (d = 8 g + 4 hi ..); one v_permlane32_swap per word hands the hi = 0 lane both halves of the even chunks and
     // the hi = 1 lane both halves of the odd ones, so each stores 8 consecutive elements - half as many store instructions
@@ -1093,6 +1111,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 int g_attn_bench = 0;   // bench library only (mjv_bench_attention_set): timing variants 1-3 of the round-2 kernel
 #endif
 
+// max_seqlen: the longest sequence in QUERY rows (= key rows unless cu_q is given)
 template <int D, bool CAUSAL>
 int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
   int e;
@@ -1203,10 +1222,25 @@ extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
   MJV_REQUIRE(((uintptr_t)d->Q | (uintptr_t)d->K | (uintptr_t)d->V | (uintptr_t)d->O) % 16 == 0,
               "attention: misaligned pointer (Q, K, V, O must be 16-byte aligned)");
   // K / V staging offsets inside one sequence are 32-bit byte offsets (row * ld * 2)
-  MJV_REQUIRE((double)d->max_seqlen * (double)(d->ldk > d->ldv ? d->ldk : d->ldv) * 2.0 < 2147483648.0,
-              "attention: max_seqlen * max(ldk, ldv) * 2 = %.0f bytes does not fit the 32-bit staging offsets",
-              (double)d->max_seqlen * (double)(d->ldk > d->ldv ? d->ldk : d->ldv) * 2.0);
+  MJV_REQUIRE(((double)d->max_seqlen + (double)(d->prefix_len > 0 ? d->prefix_len : 0)) * (double)(d->ldk > d->ldv ? d->ldk : d->ldv) * 2.0 < 2147483648.0,
+              "attention: (max_seqlen + prefix_len) * max(ldk, ldv) * 2 = %.0f bytes does not fit the 32-bit staging offsets",
+              ((double)d->max_seqlen + (double)d->prefix_len) * (double)(d->ldk > d->ldv ? d->ldk : d->ldv) * 2.0);
+  // ABI 6: suffix queries / shared key prefix - causal launches of the round-3 kernel only
+  const bool ext = d->cu_seqlens_q || d->prefix_len || d->prefix_k || d->prefix_v || d->max_seqlen_q;
+  if (ext) {
+    MJV_REQUIRE(d->prefix_len >= 0 && d->max_seqlen_q >= 0, "attention: negative prefix_len / max_seqlen_q");
+    if (!d->causal || d->kernel == 4 || d->kernel == 5) {
+      mjv_set_error("attention: cu_seqlens_q / prefix_k / prefix_v exist for causal launches of the round-3 kernel (kernel 0 / 7; 6 at head_dim 64)");
+      return MJV_E_UNSUPPORTED;
+    }
+    MJV_REQUIRE(d->prefix_len % KB == 0, "attention: prefix_len %d must be a multiple of %d (a key tile lies on one side of the boundary)", d->prefix_len, KB);
+    MJV_REQUIRE((d->prefix_len > 0) == (d->prefix_k != nullptr) && (d->prefix_len > 0) == (d->prefix_v != nullptr),
+                "attention: prefix_k and prefix_v go with prefix_len > 0");
+    MJV_REQUIRE(((uintptr_t)d->prefix_k | (uintptr_t)d->prefix_v) % 16 == 0, "attention: misaligned prefix pointer");
+    MJV_REQUIRE((d->cu_seqlens_q != nullptr) == (d->max_seqlen_q > 0), "attention: cu_seqlens_q and max_seqlen_q go together");
+  }
   AttnArgs a;
+  a.cu_q = d->cu_seqlens_q; a.Kp = d->prefix_k; a.Vp = d->prefix_v; a.prefix_len = d->prefix_len;
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
   a.qhs = d->q_head_stride; a.khs = d->k_head_stride; a.vhs = d->v_head_stride; a.ohs = d->o_head_stride;
@@ -1214,14 +1248,16 @@ extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
   a.scale = d->scale; a.round_mode = d->score_round_mode;
   hipStream_t s = (hipStream_t)stream;
   // algorithmic flops: 4 * D per (query, key) pair, halved under the causal mask (upper bound via max_seqlen)
-  const double pairs = (double)d->n_seqs * d->n_heads * (double)d->max_seqlen * d->max_seqlen * (d->causal ? 0.5 : 1.0);
+  const int max_q = d->max_seqlen_q > 0 ? d->max_seqlen_q : d->max_seqlen;   // query rows of the longest sequence
+  const double lq = max_q, lk = (double)d->max_seqlen + d->prefix_len;
+  const double pairs = (double)d->n_seqs * d->n_heads * (d->causal ? lq * (lk - lq) + 0.5 * lq * lq : lq * lk);
   const double flops = 4.0 * d->head_dim * pairs;
   if (d->head_dim == 64) {
-    if (d->causal) { MjvProfScope ps("attn_d64_causal", s, flops, 0); return launch<64, true>(a, d->n_seqs, d->max_seqlen, d->kernel, s); }
+    if (d->causal) { MjvProfScope ps("attn_d64_causal", s, flops, 0); return launch<64, true>(a, d->n_seqs, max_q, d->kernel, s); }
     MjvProfScope ps("attn_d64", s, flops, 0);
     return launch<64, false>(a, d->n_seqs, d->max_seqlen, d->kernel, s);
   }
-  if (d->causal) { MjvProfScope ps("attn_d128_causal", s, flops, 0); return launch<128, true>(a, d->n_seqs, d->max_seqlen, d->kernel, s); }
+  if (d->causal) { MjvProfScope ps("attn_d128_causal", s, flops, 0); return launch<128, true>(a, d->n_seqs, max_q, d->kernel, s); }
   MjvProfScope ps("attn_d128", s, flops, 0);
   return launch<128, false>(a, d->n_seqs, d->max_seqlen, d->kernel, s);
 }

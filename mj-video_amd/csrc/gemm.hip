@@ -1705,8 +1705,9 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
     MJV_REQUIRE(d->N % 32 == 0 && d->bias == nullptr, "gemm: SILU_MUL needs N %% 32 == 0 and no bias");
   }
   if (d->epilogue == MJV_EPI_ROPE_QKV) {
-    MJV_REQUIRE(d->rope_cos && d->rope_sin && d->rope_pos && d->rope_q && d->rope_k && d->rope_group > 0,
-                "gemm: ROPE_QKV needs cos / sin / positions / q / k / group");
+    // (rope_group 0, ABI 6: a k | v projection without q heads - the last decoder layer of a scorer needs q for a few rows only)
+    MJV_REQUIRE(d->rope_cos && d->rope_sin && d->rope_pos && d->rope_k && d->rope_group >= 0 && (d->rope_q || d->rope_group == 0),
+                "gemm: ROPE_QKV needs cos / sin / positions / k / group >= 0 (and q unless group == 0)");
     MJV_REQUIRE(d->N % ((d->rope_group + 2) * 128) == 0 && d->bias == nullptr && !d->out_rows && d->out_group <= 0,
                 "gemm: ROPE_QKV needs N %% ((group + 2) * 128) == 0, no bias, plain output rows");
     MJV_REQUIRE(d->rope_ldq % 8 == 0 && d->rope_ldk % 8 == 0 && ((uintptr_t)d->rope_q | (uintptr_t)d->rope_k |

@@ -378,8 +378,8 @@ extern "C" int mjv_bench_rmsnorm_prestat(const mjv_bf16* x, int64_t ldx, mjv_bf1
 extern "C" int mjv_rope_split_bf16(const mjv_bf16* qkv, int64_t ldqkv, mjv_bf16* q, int64_t ldq, mjv_bf16* k, int64_t ldk,
                                    const mjv_bf16* cos_tab, const mjv_bf16* sin_tab, const int32_t* positions,
                                    int32_t rows, int32_t kv_heads, int32_t group, void* stream) {
-  MJV_REQUIRE(qkv && q && k && cos_tab && sin_tab && positions, "rope: null pointer");
-  MJV_REQUIRE(rows > 0 && kv_heads > 0 && group > 0, "rope: bad sizes");
+  MJV_REQUIRE(qkv && (q || group == 0) && k && cos_tab && sin_tab && positions, "rope: null pointer");
+  MJV_REQUIRE(rows > 0 && kv_heads > 0 && group >= 0, "rope: bad sizes");
   MJV_REQUIRE(ldqkv % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0, "rope: ld alignment");
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)rows * kv_heads * (group + 1) * 8;

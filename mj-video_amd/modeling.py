@@ -368,6 +368,24 @@ class InternVLChatRewardModeling(nn.Module):
         # bound of tests/test_e2e_gpu.py::test_rank_agreement_c2) for 1 % of the step - parity with the reference comes first.
         # Both settings are tested (single layers, tiny cases, last-layer trimming).
         self.norm_fusion = False
+        # Two pieces of work a SCORER can leave out of the language tower (include/mjv.h ABI 6), both
+        # output-preserving up to the re-association of fp32 sums, both stated in bench.py's line:
+        # trim_last_layer: the heads read two late rows per sample (moe_reward.py:226-243), so the last decoder layer needs
+        #   keys / values for every row but QUERIES only from the first selected row on: its wqkv runs as a k | v projection on all
+        #   rows plus the full projection on that tail, its attention on the tail's queries.  (wo / FFN of that layer were
+        #   already evaluated on the two selected rows only.)
+        self.trim_last_layer = True
+        # prefix_cache: every prompt starts with the same tokens (system prompt + "Frame1: <img>": conversation.py:354-365,
+        #   eval_genai_mjvideo.py:132-137); under the causal mask their hidden states - and so their keys / values in all 24
+        #   layers - depend on the weights and those ids alone.  The first forward that meets a prefix computes it like any other
+        #   rows and keeps the K / V rows of its first 64 * k tokens (per layer; the copy of sample 0's rows); later forwards with
+        #   the same prefix, weights and settings leave those rows out of every GEMM / norm of the tower and attend to the
+        #   cached keys (mjv_attn_desc.prefix_k / prefix_v).  Invalidated by any parameter change (load_state_dict, .to()),
+        #   another prefix, another rotary base (dynamic NTK), another numerics setting.  False = recompute them every forward,
+        #   as the reference does.
+        self.prefix_cache = True
+        self._prefix = None          # dict(key, P, k [layers][P, kv*128], v [layers][P, ld of the layer's V rows], v_last)
+        self.prefix_cache_hits = 0   # forwards served from the cache (tests / bench report)
 
     # -- construction helpers -------------------------------------------------------------------
     @classmethod
@@ -429,6 +447,11 @@ class InternVLChatRewardModeling(nn.Module):
                 raise NotImplementedError("intermediate_size must be a multiple of 16")
             w13.append(torch.stack([w1.view(ff // 16, 16, h), w3.view(ff // 16, 16, h)], dim=1).reshape(2 * ff, h).contiguous())
         d["w13"] = w13
+        # k | v rows of the LAST decoder layer's wqkv (trim_last_layer): rows are (kv head, [q_0 .. q_{G-1}, k, v], 128)
+        lc0 = self.config.llm_config
+        KV0, G0 = lc0.num_key_value_heads, lc0.num_attention_heads // lc0.num_key_value_heads
+        wl = self.model.language_model.model.layers[-1].attention.wqkv.weight
+        d["wkv_last"] = wl.view(KV0, G0 + 2, 128, wl.shape[1])[:, G0:].reshape(KV0 * 2 * 128, wl.shape[1]).contiguous()
         if self.norm_fusion:
             def pad(v: torch.Tensor) -> torch.Tensor:      # column vectors are fetched in whole 256-tiles
                 out = torch.zeros(ops.padded_rows(v.numel()), dtype=torch.float32, device=device)
@@ -583,7 +606,12 @@ class InternVLChatRewardModeling(nn.Module):
 
         return wait
 
-    def _analyse_ids(self, ids: np.ndarray, am: Optional[np.ndarray], n_tiles: int):
+    def _analyse_ids(self, ids: np.ndarray, am: Optional[np.ndarray], n_tiles: int, prefix_lookup=None):
+        """Validates the batch and derives everything the kernels need from the token ids (packed ids, positions, row maps).
+        ``prefix_lookup`` (``forward`` with ``prefix_cache`` on): called with the ids of the batch's common prompt prefix - the
+        longest run of leading tokens shared by every sequence that ends before any <IMG_CONTEXT> / selected row, cut to a
+        multiple of 64 - and returns True when the language tower's keys / values of exactly those tokens are cached: the
+        packed rows then leave the first ``skip`` tokens of every sequence out (positions keep counting from 0)."""
         if ids.ndim != 2:
             raise ValueError(f"input_ids must be [batch, seq], got {ids.shape}")
         B, N = ids.shape
@@ -610,8 +638,7 @@ class InternVLChatRewardModeling(nn.Module):
         if valid.size and (int(valid.min()) < 0 or int(valid.max()) >= vocab):   # nn.Embedding raises here too
             raise IndexError(f"token id out of range [0, {vocab}): min {int(valid.min())}, max {int(valid.max())} "
                              "(tokenizer / checkpoint mismatch?)")
-        reward_rows, gating_rows, packed, positions, img_rows = [], [], [], [], []
-        cu = [0]
+        rs, gs, ctx = [], [], []
         for b in range(B):
             row = ids[b]
             if pad_id is None:
@@ -622,24 +649,56 @@ class InternVLChatRewardModeling(nn.Module):
             L = int(lens[b])
             if r >= L or g >= L:
                 raise ValueError(f"sample {b}: reward row {r} / gating row {g} lies in the masked tail (valid length {L})")
-            base = cu[-1]
-            reward_rows.append(base + r)
-            gating_rows.append(base + g)
-            packed.append(row[:L])
-            positions.append(np.arange(L))
-            img_rows.append(base + np.flatnonzero(row[:L] == ctx_id))
             if (row[L:] == ctx_id).any():
                 raise ValueError(f"sample {b}: <IMG_CONTEXT> tokens in the masked tail")
-            cu.append(base + L)
-        img_rows = np.concatenate(img_rows)
-        if img_rows.size != n_tiles * self.model.num_image_token:
-            raise ValueError(f"{img_rows.size} <IMG_CONTEXT> tokens in input_ids but pixel_values holds {n_tiles} tiles x "
+            rs.append(r)
+            gs.append(g)
+            ctx.append(np.flatnonzero(row[:L] == ctx_id))
+        n_ctx = sum(c.size for c in ctx)
+        if n_ctx != n_tiles * self.model.num_image_token:
+            raise ValueError(f"{n_ctx} <IMG_CONTEXT> tokens in input_ids but pixel_values holds {n_tiles} tiles x "
                              f"{self.model.num_image_token} image tokens (the reference would silently truncate, "
                              f"modeling_internvl_chat.py:178-186)")
-        return dict(B=B, N=N, total=cu[-1], max_len=int(lens.max()),
+        # the batch's common prompt prefix (system prompt + "Frame1: <img>": conversation.py:354-365, eval_genai_mjvideo.py:132-137)
+        skip, prefix_ids = 0, None
+        if prefix_lookup is not None:
+            lim = min(min(int(c[0]) if c.size else int(lens[b]) for b, c in enumerate(ctx)), min(rs), min(gs))
+            if B > 1 and lim > 0:
+                differ = np.flatnonzero((ids[1:, :lim] != ids[0, :lim]).any(axis=0))
+                if differ.size:
+                    lim = int(differ[0])
+            cand = (lim // 64) * 64
+            if cand > 0:
+                prefix_ids = np.ascontiguousarray(ids[0, :cand])
+                if prefix_lookup(prefix_ids):
+                    skip = cand
+        reward_rows, gating_rows, packed, positions, img_rows = [], [], [], [], []
+        tail_rows, tail_pos, sel_in_tail_r, sel_in_tail_g = [], [], [], []
+        cu, cu_tail = [0], [0]
+        for b in range(B):
+            row, L, r, g = ids[b], int(lens[b]), rs[b], gs[b]
+            base = cu[-1] - skip           # packed row of token j of this sample = base + j  (j >= skip)
+            reward_rows.append(base + r)
+            gating_rows.append(base + g)
+            packed.append(row[skip:L])
+            positions.append(np.arange(skip, L))
+            img_rows.append(base + ctx[b])
+            cu.append(base + L)
+            # the rows from the first selected one on: all the last decoder layer needs QUERIES for (moe_reward.py:226-243)
+            t0 = min(r, g)
+            tb = cu_tail[-1] - t0
+            tail_rows.append(base + np.arange(t0, L))
+            tail_pos.append(np.arange(t0, L))
+            sel_in_tail_r.append(tb + r)
+            sel_in_tail_g.append(tb + g)
+            cu_tail.append(tb + L)
+        return dict(B=B, N=N, total=cu[-1], max_len=int(lens.max()) - skip, skip=skip, prefix_ids=prefix_ids,
                     ids=np.concatenate(packed).astype(np.int32), positions=np.concatenate(positions).astype(np.int32),
-                    cu=np.asarray(cu, dtype=np.int32), img_rows=img_rows.astype(np.int32),
-                    sel_rows=np.asarray(reward_rows + gating_rows, dtype=np.int32))
+                    cu=np.asarray(cu, dtype=np.int32), img_rows=np.concatenate(img_rows).astype(np.int32),
+                    sel_rows=np.asarray(reward_rows + gating_rows, dtype=np.int32),
+                    tail_rows=np.concatenate(tail_rows).astype(np.int32), tail_pos=np.concatenate(tail_pos).astype(np.int32),
+                    cu_tail=np.asarray(cu_tail, dtype=np.int32), max_tail=int(np.diff(cu_tail).max()),
+                    sel_in_tail=np.asarray(sel_in_tail_r + sel_in_tail_g, dtype=np.int32))
 
     # -- towers ----------------------------------------------------------------------------------
     def _vision_tower(self, d, pixel_values: torch.Tensor, hidden: torch.Tensor, img_rows: torch.Tensor):
@@ -791,10 +850,13 @@ class InternVLChatRewardModeling(nn.Module):
 
     def _language_tower(self, d, x: torch.Tensor, cu: torch.Tensor, positions: torch.Tensor, max_len: int,
                         sel_rows: Optional[torch.Tensor] = None, padded_len: Optional[int] = None,
-                        only_layer: Optional[int] = None):
+                        only_layer: Optional[int] = None, tail=None, prefix=None, snapshot=None):
         """24 decoder layers in place on the packed rows ``x``.  With ``sel_rows`` (the 2 rows per sample the heads
         read) the LAST layer runs wo / FFN only on those rows - every other row of its output is never used
-        (moe_reward.py:211,229,243) - and the [len(sel_rows), hidden] result is returned instead of ``x``."""
+        (moe_reward.py:211,229,243) - and the [len(sel_rows), hidden] result is returned instead of ``x``.
+        ``tail`` (with ``sel_rows``; ``trim_last_layer``) = (tail_rows, tail_pos, cu_tail, max_tail, sel_in_tail): the last
+        layer computes queries only for those rows.  ``prefix`` = the cached keys / values of the prompt prefix the packed rows
+        leave out (``prefix_cache``); ``snapshot`` = (P, store): keep rows [0, P) of every layer's K / V in ``store``."""
         dev = x.device
         lc = self.config.llm_config
         lm = self.model.language_model.model
@@ -812,11 +874,44 @@ class InternVLChatRewardModeling(nn.Module):
         scale = 1.0 / math.sqrt(hd)
         v_view = qkv[:, (G + 1) * hd:]
         last = len(lm.layers) - 1
+        mode = 2 if self.attention_scores == "flash" else 1
         for li, layer in enumerate(lm.layers):
             if only_layer is not None and li != only_layer:   # (run_llm_layer: one layer on given rows)
                 continue
             lfold = d["llm_fold"][li] if self.norm_fusion else None
             exp8 = self._exp_fp8_attn_side and self.ffn_format == "mxfp8" and lfold is None
+            trim_here = li == last and sel_rows is not None and self.debug_probes is None and only_layer is None
+            pk = prefix["k"][li] if prefix is not None else None
+            if trim_here and tail is not None and lfold is None and not exp8:
+                # last layer, queries only where the heads will read (trim_last_layer): k | v projection (+ rotary on k) on every
+                # row, the full wqkv on the tail rows, attention of the tail's queries over all keys
+                tail_rows, tail_pos, cu_tail, max_tail, sel_in_tail = tail
+                nt, ns = tail_rows.numel(), sel_rows.numel()
+                kv = self._buf("llm_kv_last", n, 2 * KV * hd, dev)
+                ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
+                ops.gemm(hn, d["wkv_last"], kv, EPI_ROPE_QKV, rope=(cos, sin, positions, None, k, 0))
+                if snapshot is not None:
+                    snapshot[1]["k"].append(k[:snapshot[0]].clone())
+                    snapshot[1]["v_last"] = kv[:snapshot[0]].clone()
+                hn_t = self._buf("llm_hn_tail", nt, hdim, dev)
+                qkv_t = self._buf("llm_qkv_tail", nt, (H + 2 * KV) * hd, dev)
+                q_t = self._buf("llm_q_tail", nt, H * hd, dev)
+                k_t = self._buf("llm_k_tail", nt, KV * hd, dev)
+                att_t = self._buf("llm_att_tail", nt, H * hd, dev)
+                ops.embed_gather(tail_rows, hn, hn_t, -1)
+                ops.gemm(hn_t, layer.attention.wqkv.weight, qkv_t, EPI_ROPE_QKV, rope=(cos, sin, tail_pos, q_t, k_t, G))
+                ops.attention(q_t, k, kv[:, hd:], att_t, cu, max_len, H, G, hd, True, scale, mode, v_head_stride=2 * hd,
+                              cu_seqlens_q=cu_tail, max_seqlen_q=max_tail,
+                              prefix_k=pk, prefix_v=(prefix["v_last"][:, hd:] if prefix is not None else None))
+                att_s = self._buf("llm_att_sel", ns, hdim, dev)
+                x_s = self._buf("llm_x_sel", ns, hdim, dev)
+                hn_s = self._buf("llm_hn_sel", ns, hdim, dev)
+                act_s = self._buf("llm_act_sel", ns, ff, dev)
+                ops.embed_gather(sel_in_tail, att_t, att_s, -1)
+                ops.embed_gather(sel_rows, x, x_s, -1)
+                ops.gemm(att_s, layer.attention.wo.weight, x_s, EPI_SCALE_RES, res=x_s)
+                self._llm_ffn(d, li, layer, x_s, hn_s, act_s, "sel")
+                return x_s
             # wqkv with the rotary embedding + GQA de-interleave in its epilogue: q / k go (rotated) to their own buffers,
             # v stays in its columns of qkv (modeling_internlm2.py:359-381)
             if lfold is not None:
@@ -831,11 +926,14 @@ class InternVLChatRewardModeling(nn.Module):
             else:
                 ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
                 ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_ROPE_QKV, rope=(cos, sin, positions, q, k, G))
-            ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, 2 if self.attention_scores == "flash" else 1,
-                          v_head_stride=(G + 2) * hd)
+            if snapshot is not None:   # rows [0, P) of sample 0: the prompt prefix's keys (rotated) and values of this layer
+                snapshot[1]["k"].append(k[:snapshot[0]].clone())
+                snapshot[1]["v"].append(qkv[:snapshot[0]].clone())
+            ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, mode, v_head_stride=(G + 2) * hd,
+                          prefix_k=pk, prefix_v=(prefix["v"][li][:, (G + 1) * hd:] if prefix is not None else None))
             if self.debug_probes is not None and li == 0:   # operands / result of the first causal attention (parity tests)
                 self.debug_probes["llm_attn0"] = dict(q=q.clone(), k=k.clone(), v=v_view.clone(), out=hn.clone(), kv_heads=KV)
-            if li == last and sel_rows is not None and self.debug_probes is None and only_layer is None:
+            if trim_here:
                 ns = sel_rows.numel()
                 att_s = self._buf("llm_att_sel", ns, hdim, dev)
                 x_s = self._buf("llm_x_sel", ns, hdim, dev)
@@ -893,23 +991,51 @@ class InternVLChatRewardModeling(nn.Module):
                                if self.use_gemm_workspace else None)
         vit = self._vision_tower_launch(d, pixel_values)     # (needs no ids: enqueued before the host waits for them)
         input_ids, attention_mask = host_ids()
-        info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0])  # host arrays (see forward)
-        B, total = info["B"], info["total"]
+        trimmed = self.debug_probes is None
         lc = self.config.llm_config
         hdim = lc.hidden_size
+        # what the cached prefix rows depend on besides their ids: the weights (as _prepare tracks them), the rotary base
+        # (dynamic NTK may have replaced it), every numerics setting, and which buffer the last layer's values live in
+        tail_form = bool(trimmed and self.trim_last_layer and not self.norm_fusion and not self._exp_fp8_attn_side)
+        self._rope_tables(int(input_ids.shape[1]), dev)   # (advances the rotary state exactly as the tower will see it)
+        settings = (self._derived_sig, self._rope_state["base"], self.attention_scores, self.ffn_format, bool(self.norm_fusion),
+                    bool(self._exp_fp8_attn_side), bool(self.use_gemm_workspace), tail_form, str(dev))
+        use_prefix = bool(self.prefix_cache and trimmed)
+
+        def lookup(prefix_ids: np.ndarray) -> bool:
+            c = self._prefix
+            return (c is not None and c["settings"] == settings and c["ids"].shape == prefix_ids.shape
+                    and bool((c["ids"] == prefix_ids).all()))
+
+        info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0], lookup if use_prefix else None)  # host arrays
+        B, total = info["B"], info["total"]
+        prefix = self._prefix if info["skip"] else None
+        snapshot = None
+        if use_prefix and prefix is None and info["prefix_ids"] is not None:
+            # a prefix this model has no keys / values for (first forward, new weights, new prompt): computed like every other
+            # row in THIS forward, and its rows kept for the next ones
+            snapshot = (int(info["prefix_ids"].shape[0]), dict(k=[], v=[], v_last=None))
+        if prefix is not None:
+            self.prefix_cache_hits += 1
 
         def up(a):
             return torch.from_numpy(a).to(dev, non_blocking=True)
 
         ids, positions, cu = up(info["ids"]), up(info["positions"]), up(info["cu"])
         img_rows, sel_rows = up(info["img_rows"]), up(info["sel_rows"])
+        tail = None
+        if tail_form:
+            tail = (up(info["tail_rows"]), up(info["tail_pos"]), up(info["cu_tail"]), info["max_tail"], up(info["sel_in_tail"]))
         hidden = self._buf("llm_x", total, hdim, dev)
         ops.embed_gather(ids, self.model.language_model.model.tok_embeddings.weight, hidden, self.model.img_context_token_id)
         self._vision_tower_splice(vit, hidden, img_rows)
         if self.debug_probes is not None and probes_ok:
             self.debug_probes["llm_embed"] = hidden.clone()
-        trimmed = self.debug_probes is None
-        last_x = self._language_tower(d, hidden, cu, positions, info["max_len"], sel_rows if trimmed else None, padded_len=info["N"])
+        last_x = self._language_tower(d, hidden, cu, positions, info["max_len"], sel_rows if trimmed else None, padded_len=info["N"],
+                                      tail=tail, prefix=prefix, snapshot=snapshot)
+        if snapshot is not None:
+            st = snapshot[1]
+            self._prefix = dict(settings=settings, ids=info["prefix_ids"].copy(), P=snapshot[0], k=st["k"], v=st["v"], v_last=st["v_last"])
 
         # final RMSNorm only on the 2 rows per sample the heads read (hidden_states[-1] is post-norm, moe_reward.py:211)
         h_r, h_g = outs["hidden_state"][lo:lo + B], outs["prompt_embedding"][lo:lo + B]

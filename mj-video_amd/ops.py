@@ -181,8 +181,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         assert positions.dtype == torch.int32 and positions.is_cuda and positions.numel() >= d.M
         assert cos.shape[1] == 128 and cos.is_contiguous() and sin.is_contiguous()
         d.rope_cos, d.rope_sin, d.rope_pos = cos.data_ptr(), sin.data_ptr(), positions.data_ptr()
-        d.rope_q, d.rope_k = q_out.data_ptr(), k_out.data_ptr()
-        d.rope_ldq, d.rope_ldk, d.rope_group = _row_stride(q_out), _row_stride(k_out), group
+        d.rope_q, d.rope_k = _p(q_out), k_out.data_ptr()   # (q_out None with group 0: a k | v projection, no q heads)
+        d.rope_ldq, d.rope_ldk, d.rope_group = (_row_stride(q_out) if q_out is not None else 0), _row_stride(k_out), group
     if folded_norm is not None:
         for t, n in zip(folded_norm, (d.M, d.M, d.N, d.N)):
             assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous() and t.numel() >= padded_rows(n), (t.shape, n)
@@ -220,9 +220,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               max_seqlen: int, n_heads: int, kv_group: int, head_dim: int, causal: bool, scale: float,
               score_round_mode: int, q_head_stride: Optional[int] = None, k_head_stride: Optional[int] = None,
               v_head_stride: Optional[int] = None, o_head_stride: Optional[int] = None,
-              kernel: Optional[int] = None) -> torch.Tensor:
+              kernel: Optional[int] = None, cu_seqlens_q: Optional[torch.Tensor] = None, max_seqlen_q: int = 0,
+              prefix_k: Optional[torch.Tensor] = None, prefix_v: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q/k/v/out are 2-D views [rows, >= heads*head_dim] (row stride honoured, first head at column 0).
-    ``kernel``: 0 automatic, 4 / 5 = the round-1 / round-2 kernels (default: the calling thread's ``attention_set_variant``)."""
+    ``kernel``: 0 automatic, 4 / 5 = the round-1 / round-2 kernels (default: the calling thread's ``attention_set_variant``).
+    Causal only (include/mjv.h ABI 6): ``cu_seqlens_q`` / ``max_seqlen_q`` - the queries are the LAST rows of every sequence,
+    packed at those offsets of q / out; ``prefix_k`` / ``prefix_v`` [P, ...] - P (a multiple of 64) shared keys / values in front of
+    every sequence's own rows, same row stride and head stride as k / v."""
     _chk_bf16(q, k, v, out)
     assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_cuda
     lib = load_library()
@@ -238,6 +242,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     d.n_heads, d.kv_group, d.head_dim = n_heads, kv_group, head_dim
     d.causal, d.scale, d.score_round_mode = int(causal), scale, score_round_mode
     d.kernel = _tls.attn_kernel if kernel is None else kernel
+    if cu_seqlens_q is not None:
+        assert cu_seqlens_q.dtype == torch.int32 and cu_seqlens_q.is_cuda and cu_seqlens_q.numel() == cu_seqlens.numel()
+        d.cu_seqlens_q, d.max_seqlen_q = cu_seqlens_q.data_ptr(), max_seqlen_q
+    if prefix_k is not None or prefix_v is not None:
+        _chk_bf16(prefix_k, prefix_v)
+        assert _row_stride(prefix_k) == d.ldk and _row_stride(prefix_v) == d.ldv and prefix_k.shape[0] == prefix_v.shape[0]
+        d.prefix_k, d.prefix_v, d.prefix_len = prefix_k.data_ptr(), prefix_v.data_ptr(), prefix_k.shape[0]
     with torch.cuda.device(out.device):
         check(lib.mjv_attention_bf16(C.byref(d), _stream(out)), "mjv_attention_bf16")
     return out

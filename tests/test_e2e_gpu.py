@@ -511,6 +511,97 @@ def test_last_layer_trimming_is_invisible(cuda, fused):
         assert e < 0.045, (f, e)
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "mxfp8"])
+def test_prefix_cache_is_invisible_and_invalidates(cuda, fmt):
+    """``model.prefix_cache``: the keys / values of the constant prompt prefix are computed by the first
+    forward that meets it and reused by the next ones, which leave those rows out of the language tower.  At 2B dims @224^2
+    (5 videos of different lengths, then another batch):
+      * the first (snapshot) forward is the uncached computation - every field bit-identical to ``prefix_cache = False``;
+      * later forwards hit the cache and, with no GEMM slicing K, are STILL bit-identical (a row's sums, a query's softmax do
+        not depend on which other rows the launch holds); with K-slicing on they differ like any re-associated fp32 sum;
+      * the cached K / V rows are bit-identical to the prefix rows a fresh uncached forward of ANOTHER batch computes;
+      * invalidation: new weights (load_state_dict), another prefix, another attention numerics setting -> recomputed."""
+    from mj_video_amd import synth
+    cfg = make_cfg("2b", 224)
+    sd = synth.synth_state_dict(cfg, seed=0, lm_head=False)
+    sd["model.language_model.output.weight"] = torch.zeros(1, dtype=torch.bfloat16).expand(
+        cfg.llm_config.vocab_size, cfg.llm_config.hidden_size)
+    model = build_hip_model(cfg, sd, cuda)
+    model.set_ffn_format(fmt)
+    vids = [dict(video_idx=i, n_tiles=t, caption_seed=i) for i, t in enumerate([8, 6, 8, 3, 5])]
+    px, ids, mask, _ = case_inputs(cfg, vids, 77, 224)
+    px, ids, mask = px.to(cuda), ids.to(cuda), mask.to(cuda)
+    vids2 = [dict(video_idx=10 + i, n_tiles=t, caption_seed=20 + i) for i, t in enumerate([2, 8, 7])]
+    px2, ids2, mask2, _ = case_inputs(cfg, vids2, 78, 224)
+    px2, ids2, mask2 = px2.to(cuda), ids2.to(cuda), mask2.to(cuda)
+
+    def fields_equal(a, b):
+        return [f for f in FIELDS if not torch.equal(getattr(a, f), getattr(b, f))]
+
+    try:
+        model.use_gemm_workspace = False
+        model.prefix_cache = False
+        ref, ref2 = model.forward(px, ids, mask), model.forward(px2, ids2, mask2)
+        assert model._prefix is None and model.prefix_cache_hits == 0
+        model.prefix_cache = True
+        first = model.forward(px, ids, mask)
+        assert model.prefix_cache_hits == 0 and model._prefix is not None and model._prefix["P"] == 64
+        assert fields_equal(first, ref) == []
+        cached_k = [t.clone() for t in model._prefix["k"]]
+        cached_v_last = model._prefix["v_last"].clone()
+        assert len(cached_k) == cfg.llm_config.num_hidden_layers
+        again, other = model.forward(px, ids, mask), model.forward(px2, ids2, mask2)
+        assert model.prefix_cache_hits == 2
+        assert fields_equal(again, ref) == [] and fields_equal(other, ref2) == []
+        # the prefix rows of ANOTHER batch, computed from scratch, are the cached rows
+        model._prefix = None
+        model.forward(px2, ids2, mask2)
+        assert all(torch.equal(a, b) for a, b in zip(cached_k, model._prefix["k"])) and torch.equal(cached_v_last, model._prefix["v_last"])
+        # invalidation 1: another attention numerics setting
+        hits = model.prefix_cache_hits
+        model.attention_scores = "eager"
+        eager = model.forward(px, ids, mask)
+        assert model.prefix_cache_hits == hits and model._prefix["settings"][2] == "eager"
+        model.prefix_cache = False
+        assert fields_equal(eager, model.forward(px, ids, mask)) == []
+        model.prefix_cache = True
+        model.attention_scores = "flash"
+        # invalidation 2: another prefix (one system token changed in every sample)
+        model.forward(px, ids, mask)
+        hits = model.prefix_cache_hits
+        ids3 = ids.clone()
+        ids3[:, 7] += 1
+        changed = model.forward(px, ids3, mask)
+        assert model.prefix_cache_hits == hits
+        assert model.forward(px, ids3, mask) is not None and model.prefix_cache_hits == hits + 1
+        model.prefix_cache = False
+        assert fields_equal(changed, model.forward(px, ids3, mask)) == []
+        model.prefix_cache = True
+        # invalidation 3: new weights
+        model.forward(px, ids, mask)
+        hits = model.prefix_cache_hits
+        sd2 = synth.synth_state_dict(cfg, seed=1, lm_head=False)
+        sd2["model.language_model.output.weight"] = sd["model.language_model.output.weight"]
+        model.load_state_dict(sd2, strict=True)
+        new_w = model.forward(px, ids, mask)
+        assert model.prefix_cache_hits == hits and fields_equal(new_w, ref) != []
+        hit = model.forward(px, ids, mask)
+        assert model.prefix_cache_hits == hits + 1 and fields_equal(hit, new_w) == []
+    finally:
+        model.use_gemm_workspace = True
+    # with K-slicing on: re-association noise only (bound as in test_last_layer_trimming_is_invisible)
+    model.prefix_cache = False
+    plain = model.forward(px, ids, mask)
+    model.prefix_cache = True
+    model.forward(px, ids, mask)
+    sliced = model.forward(px, ids, mask)
+    assert model._prefix["settings"][6] is True
+    for f in ("hidden_state", "prompt_embedding"):
+        e = rel_l2(getattr(sliced, f).float().cpu().numpy(), getattr(plain, f).float().cpu().numpy())
+        print(f"prefix cache on vs off, K-slicing on, {fmt}, {f}: relative L2 {e:.4f}")
+        assert e < 0.045, (f, e)
+
+
 def test_k_sliced_path_is_no_further_from_fp32(cuda):
     """the pairwise bound above (K-sliced vs unsliced, 4.5 %) cannot tell a small systematic error of the K-sliced / skinny
     paths from re-association noise; the exact-integer kernel tests are the correctness gate, and this is the end-to-end

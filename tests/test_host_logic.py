@@ -22,7 +22,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib = _lib.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mjv_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.mjv_abi_version() == _lib.ABI_VERSION == 6
     assert lib.mjv_arch() == b"gfx950"
     assert os.path.dirname(path).endswith("mj-video_amd")  # in-tree, so the driver sees it loaded
     # ABI 4: no process-wide setter in the product header, and the product library neither exports the measurement switches
@@ -319,6 +319,56 @@ def test_analyse_ids_packing():
     model.model.img_context_token_id = None
     with pytest.raises(ValueError, match="img_context_token_id"):
         model._analyse_ids(ids.numpy(), mask.numpy().astype(bool), 6)
+
+
+def test_analyse_ids_prefix_skip_and_tail():
+    """the host side of ABI 6's two trimmings: the common prompt prefix (cut to a multiple of 64, never reaching an <IMG_CONTEXT>
+    or a selected row) is offered to the cache lookup and, on a hit, left out of the packed rows while positions keep their
+    absolute values; the tail = rows from the first selected one on, with the selected rows' indices inside it"""
+    cfg = make_cfg("tiny", 56)
+    model = InternVLChatRewardModeling.from_config(cfg)
+    model.config.pad_token_id = synth.PAD_ID
+    model.model.img_context_token_id = synth.IMG_CONTEXT_ID
+    a, b = synth.synth_input_ids(16, 1), synth.synth_input_ids(8, 2)
+    ids, mask = synth.pad_batch([a, b])
+    ids_np, am = ids.numpy(), mask.numpy().astype(bool)
+    La, Lb = a.shape[1], b.shape[1]
+    first_ctx = int(np.flatnonzero(ids_np[0] == synth.IMG_CONTEXT_ID)[0])
+    assert first_ctx == 71                       # BOS + system turn + "user\n Frame1: <img>" of the synthetic prompt
+    seen = []
+    info = model._analyse_ids(ids_np, am, 6, lambda p: seen.append(p.copy()) or False)      # offered, refused
+    assert len(seen) == 1 and seen[0].tolist() == ids_np[0, :64].tolist() and info["skip"] == 0
+    assert info["prefix_ids"].tolist() == ids_np[0, :64].tolist()
+    plain = model._analyse_ids(ids_np, am, 6)
+    for k in ("ids", "positions", "cu", "img_rows", "sel_rows", "tail_rows", "cu_tail", "sel_in_tail"):
+        assert np.array_equal(info[k], plain[k]), k
+    assert plain["prefix_ids"] is None and plain["skip"] == 0
+    # tail: rows L - 5 .. L - 1 of both samples; reward row = last, gating row = first of the tail
+    assert plain["cu_tail"].tolist() == [0, 5, 10] and plain["max_tail"] == 5
+    assert plain["tail_rows"].tolist() == list(range(La - 5, La)) + list(range(La + Lb - 5, La + Lb))
+    assert plain["tail_pos"].tolist() == list(range(La - 5, La)) + list(range(Lb - 5, Lb))
+    assert plain["sel_in_tail"].tolist() == [4, 9, 0, 5]
+    hit = model._analyse_ids(ids_np, am, 6, lambda p: True)
+    assert hit["skip"] == 64 and hit["total"] == La + Lb - 128 and hit["max_len"] == La - 64
+    assert hit["cu"].tolist() == [0, La - 64, La + Lb - 128]
+    assert hit["positions"][0] == 64 and hit["positions"][La - 64] == 64 and hit["positions"][La - 65] == La - 1
+    assert np.array_equal(hit["ids"], np.concatenate([ids_np[0, 64:La], ids_np[1, 64:Lb]]))
+    assert (hit["ids"][hit["img_rows"]] == synth.IMG_CONTEXT_ID).all() and hit["img_rows"].size == 24
+    assert hit["sel_rows"].tolist() == [La - 65, La + Lb - 129, La - 69, La + Lb - 133]
+    assert hit["tail_rows"].tolist() == list(range(La - 69, La - 64)) + list(range(La + Lb - 133, La + Lb - 128))
+    assert hit["tail_pos"].tolist() == plain["tail_pos"].tolist() and hit["sel_in_tail"].tolist() == [4, 9, 0, 5]
+    # samples that differ inside the first 64 tokens share no cacheable prefix; a difference at token 70 leaves 64
+    other = ids_np.copy()
+    other[1, 10] += 1
+    assert model._analyse_ids(other, am, 6, lambda p: True)["skip"] == 0
+    other = ids_np.copy()
+    other[1, 70] += 1
+    assert model._analyse_ids(other, am, 6, lambda p: True)["skip"] == 64
+    # a 130-token common prefix is cut to 128
+    long_a = torch.cat([a[:, :60], a[:, 1:61], a[:, 1:]], dim=1)
+    long_b = torch.cat([b[:, :60], b[:, 1:61], b[:, 1:]], dim=1)
+    lids, lmask = synth.pad_batch([long_a, long_b])
+    assert model._analyse_ids(lids.numpy(), lmask.numpy().astype(bool), 6, lambda p: True)["skip"] == 128
 
 
 def test_custom_output_access():

@@ -5,6 +5,7 @@ loop and a CPU GEMM, which can flip the final rounding by 1 ulp (2 ulps after a 
 """
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -845,6 +846,66 @@ def test_attention_long_context_c4(cuda, attn_variant):
         rel = (got - ref).norm() / ref.norm()
         assert rel.item() < 6e-3, (h, rel.item())
         assert (got - ref).abs().max().item() < 0.03
+
+
+@pytest.mark.parametrize("D,H,G", [(128, 4, 2), (64, 2, 1)])
+@pytest.mark.parametrize("P,lens,qlens", [
+    (0, [2186, 700, 131], [5, 700, 64]),          # suffix queries only (the last decoder layer of a scorer)
+    (64, [2122, 636, 67, 1], [2122, 636, 67, 1]),  # a shared 64-key prefix, every own row a query (the prompt-prefix cache)
+    (128, [2058, 300, 65], [5, 1, 33]),            # both
+    (64, [700, 64], [700, 3]),
+])
+def test_attention_suffix_queries_and_shared_prefix(cuda, D, H, G, P, lens, qlens):
+    """ABI 6 (causal): queries = the LAST rows of a sequence (cu_seqlens_q), keys = a SHARED prefix (prefix_k / prefix_v, a
+    multiple of 64 rows) followed by the sequence's own rows.  Reference = the ordinary launch of the same kernel over the
+    concatenated rows [prefix | own] of every sequence: include/mjv.h promises the same arithmetic with the same key-tile
+    boundaries, so the selected rows must agree BIT FOR BIT (both score modes); and that ordinary launch is itself held to the
+    fp32 reference by test_attention.  Older kernels and non-causal launches refuse the fields."""
+    from mj_video_amd import ops, _lib
+    KVH = H // G
+    g = torch.Generator().manual_seed(17 + P)
+    pk, pv = rnd(max(P, 1), KVH * D, seed=5)[:P], rnd(max(P, 1), KVH * D, seed=6)[:P]
+    n_own = sum(lens)
+    k_own, v_own = rnd(n_own, KVH * D, seed=7), rnd(n_own, KVH * D, seed=8)
+    q_own = rnd(n_own, H * D, seed=9)          # a query for every own row; the extended launch uses the last qlens[i] of each
+    q_pre = rnd(max(P, 1), H * D, seed=10)[:P]
+    # the concatenated problem
+    ks, vs, qs, full_lens = [], [], [], []
+    o = 0
+    for L in lens:
+        ks += [pk, k_own[o:o + L]]
+        vs += [pv, v_own[o:o + L]]
+        qs += [q_pre, q_own[o:o + L]]
+        full_lens.append(P + L)
+        o += L
+    kf, vf, qf = torch.cat(ks).to(cuda), torch.cat(vs).to(cuda), torch.cat(qs).to(cuda)
+    cu_full = torch.tensor([0] + list(np.cumsum(full_lens)), dtype=torch.int32, device=cuda)
+    cu_k = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=cuda)
+    cu_q = torch.tensor([0] + list(np.cumsum(qlens)), dtype=torch.int32, device=cuda)
+    q_sel = torch.cat([q_own[o + L - lq:o + L] for o, L, lq in zip(np.cumsum([0] + lens[:-1]), lens, qlens)]).to(cuda)
+    scale = D ** -0.5
+    for mode in (2, 1):
+        full = torch.empty(qf.shape[0], H * D, dtype=BF, device=cuda)
+        ops.attention(qf, kf, vf, full, cu_full, max(full_lens), H, G, D, True, scale, mode)
+        want = torch.cat([full[int(cu_full[i + 1]) - lq:int(cu_full[i + 1])] for i, lq in enumerate(qlens)])
+        got = torch.full((sum(qlens), H * D), float("nan"), dtype=BF, device=cuda)
+        kw = {}
+        if qlens != lens:
+            kw.update(cu_seqlens_q=cu_q, max_seqlen_q=max(qlens))
+        if P:
+            kw.update(prefix_k=pk.to(cuda), prefix_v=pv.to(cuda))
+        ops.attention(q_sel, k_own.to(cuda), v_own.to(cuda), got, cu_k, max(lens), H, G, D, True, scale, mode, **kw)
+        assert torch.isfinite(got.float()).all()
+        assert torch.equal(got, want), (mode, (got.float() - want.float()).abs().max().item())
+    if kw:
+        for bad in (dict(kernel=5), dict(causal=False)):
+            with pytest.raises(_lib.MjvLibraryError, match="causal launches of the round-3 kernel"):
+                ops.attention(q_sel, k_own.to(cuda), v_own.to(cuda), got, cu_k, max(lens), H, G, D, bad.get("causal", True), scale, 1,
+                              kernel=bad.get("kernel"), **kw)
+    if P:
+        with pytest.raises(_lib.MjvLibraryError, match="multiple of 64"):
+            ops.attention(q_sel, k_own.to(cuda), v_own.to(cuda), got, cu_k, max(lens), H, G, D, True, scale, 2,
+                          prefix_k=pk[:P - 1].to(cuda), prefix_v=pv[:P - 1].to(cuda), **{k: v for k, v in kw.items() if k.startswith(("cu", "max"))})
 
 
 # ------------------------------------------------------------------------------------------ event profiler
