@@ -46,6 +46,8 @@ struct Gemm8Args {
   int tiles_m, tiles_n;
   int gm;
   int nt_store;
+  long a_grp_max;                    // last valid 64-row scale group relative to As (As / A may point at peeled tail rows)
+  float* ws; int split;              // K-sliced launches: fp32 accumulator images (gemm.hip's layout), slices per tile
 };
 
 MJV_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -67,9 +69,8 @@ MJV_DEV float gelu_lut(float xf, const u16* tab) {
   return __uint_as_float(in_tab ? (t << 16) : other);
 }
 
-// XCD-aware tile order (gemm.hip tile_of_vblock)
-MJV_DEV void tile_of_block(const Gemm8Args& p, int& tm, int& tn) {
-  const int nwg = gridDim.x, b = blockIdx.x;
+// XCD-aware tile order (gemm.hip tile_of_vblock): b-th of nwg tiles
+MJV_DEV void tile_of_block(const Gemm8Args& p, const int nwg, const int b, int& tm, int& tn) {
   const int GM = p.gm;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
   const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
@@ -147,18 +148,25 @@ MJV_DEV f32x4 mfma8(const i32x8& a, const i32x8& b, const f32x4& c, int sa, int 
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, sa, OB, sb);
 }
 
-template <int EPI, bool OUT8>
+// SPLIT: the launch has p.split K-slices per tile (workgroup b = tile b / split, slice b % split: gemm.hip's VAR 7): the
+// accumulators go to the fp32 workspace as they sit in registers and splitk_finish256f8_kernel sums them in slice order
+template <int EPI, bool OUT8, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
   static_assert(!(OUT8 && EPI == MJV_EPI_SCALE_RES), "the residual epilogue writes the bf16 stream");
+  static_assert(!SPLIT || (EPI == MJV_EPI_BIAS && !OUT8), "one epilogue-free instantiation serves every sliced launch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, l4 = lane >> 4;
   int tm, tn;
-  tile_of_block(p, tm, tn);
+  const int tile_id = SPLIT ? (int)blockIdx.x / p.split : (int)blockIdx.x;
+  const int slice = SPLIT ? (int)blockIdx.x % p.split : 0;
+  tile_of_block(p, SPLIT ? (int)gridDim.x / p.split : (int)gridDim.x, tile_id, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = p.K / BK;
+  const int nk_all = p.K / BK;
+  const int kt0 = SPLIT ? (int)((long)nk_all * slice / p.split) : 0;          // this slice's K-tiles [kt0, kt0 + nk)
+  const int nk = (SPLIT ? (int)((long)nk_all * (slice + 1) / p.split) : nk_all) - kt0;
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -196,6 +204,12 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
   }
   StagePtrs sp;
   init_stage_ptrs(sp, p, m0, n0, wave, lane);
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int which = 0; which < 4; ++which)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sp.src[which][i] += kt0 * BK;
+  }
   if constexpr (EPI == MJV_EPI_BIAS_GELU) {
     static_assert(MJV_GELU_TABLE_LEN % 8 == 0 && MJV_GELU_TABLE_LEN / 8 <= 1024, "two 16-byte chunks per thread cover the table");
 #pragma unroll
@@ -212,10 +226,11 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
   {
     const bool is_w = wave < 4;
     const long groups = is_w ? p.w_groups : p.a_groups;
+    const long last = is_w ? p.w_groups - 1 : p.a_grp_max;
     long grp = ((is_w ? n0 : m0) >> 6) + (wave & 3);
-    grp = grp < groups ? grp : groups - 1;   // (groups beyond the problem: rows the epilogue never stores)
-    sc_src = (is_w ? p.Ws : p.As) + grp * 256 + (lane & 15) * 16;
+    grp = grp < last ? grp : last;   // (groups beyond the problem: rows the epilogue never stores)
     sc_stride = groups * 256;
+    sc_src = (is_w ? p.Ws : p.As) + grp * 256 + (lane & 15) * 16 + (long)kt0 * sc_stride;
   }
   auto stage_scales = [&](int t) {
     if (t < nk && lane < 16)
@@ -305,6 +320,14 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
   }
   if (wr == 0) MJV_BARRIER();
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) in the form the compiler's wait-count pass reads (gemm.hip)
+  if constexpr (SPLIT) {
+    f32x4* img = (f32x4*)p.ws + ((long)tile_id * p.split + slice) * (32 * 512) + tid;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) img[(i * 4 + j) * 512] = acc[i][j];
+    return;
+  }
 #undef MJV_FRAG
 #undef MJV_LOAD_A
 #undef MJV_LOAD_W
@@ -445,6 +468,97 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
   }
 }
 
+// Second half of a K-sliced launch.  A wave finishes 16 rows x 32 output columns (one MXFP8 block per row): lane = row
+// (lane & 15) x 8-column group (lane >> 4), so the slices' images are read in 256-byte runs (16 rows of one fragment column
+// group) and a block's four column groups sit in lanes l, l + 16, l + 32, l + 48.  Sums the slices in slice order
+// (deterministic), then the epilogue of gemm256f8_kernel - same operations, same rounding points - and, for an MXFP8 output,
+// the block quantiser.  Workgroup = 4 waves = 16 rows x 128 output columns.
+template <int EPI, bool OUT8>
+__global__ __launch_bounds__(256) void splitk_finish256f8_kernel(Gemm8Args p) {
+  constexpr int OUT_COLS = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
+  constexpr int CB = OUT_COLS / 128;                // workgroups per 16-row group of a tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_tile = 16 * CB;
+  const int tile_id = (int)blockIdx.x / per_tile, rest = (int)blockIdx.x % per_tile;
+  int tm, tn;
+  tile_of_block(p, (int)gridDim.x / per_tile, tile_id, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int ml = (rest / CB) * 16 + (lane & 15);                       // row inside the tile
+  const int oc = ((rest % CB) * 4 + wave) * 32 + (lane >> 4) * 8;      // first of this lane's 8 output columns inside the tile
+  const int nout0 = (EPI == MJV_EPI_SILU_MUL) ? n0 / 2 : n0;
+  const int nlim = (EPI == MJV_EPI_SILU_MUL) ? p.N / 2 : p.N;
+  const int n = nout0 + oc;
+  // image index (in f32x4) of (row ml, tile column tc % 4 == 0): fragment (i, j) of thread (wr, wc, l4, l15) of the GEMM workgroup
+  auto img_idx = [&](int tc) {
+    const int wr = ml >> 7, i = (ml >> 4) & 7, l15 = ml & 15;
+    const int wc = tc >> 6, j = (tc >> 4) & 3, l4 = (tc >> 2) & 3;
+    return (i * 4 + j) * 512 + (wr * 4 + wc) * 64 + l4 * 16 + l15;
+  };
+  constexpr int NF = (EPI == MJV_EPI_SILU_MUL) ? 4 : 2;
+  int idx[NF];
+  if constexpr (EPI == MJV_EPI_SILU_MUL) {
+    // output columns 16 a + b of a 32-column group come from tile columns 32 a + b (gate) and 32 a + 16 + b (up)
+    const int tg = (oc >> 4) * 32 + (oc & 15);
+    idx[0] = img_idx(tg); idx[1] = img_idx(tg + 4); idx[2] = img_idx(tg + 16); idx[3] = img_idx(tg + 20);
+  } else {
+    idx[0] = img_idx(oc); idx[1] = img_idx(oc + 4);
+  }
+  const f32x4* img = (const f32x4*)p.ws + (long)tile_id * p.split * (32 * 512);
+  f32x4 fr[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) fr[f] = img[idx[f]];
+  for (int sl = 1; sl < p.split; ++sl) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) fr[f] += img[(long)sl * (32 * 512) + idx[f]];
+  }
+  const bool live = m0 + ml < p.M && n < nlim;      // (every lane stays for the block exchange of an MXFP8 output)
+  float v[8];
+  if constexpr (EPI == MJV_EPI_SILU_MUL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = rbf(silu(rbf(fr[e >> 2][e & 3]))) * rbf(fr[2 + (e >> 2)][e & 3]);
+  } else {
+    float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias && live) unpack8(*(const u32x4*)(p.bias + n), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fr[e >> 2][e & 3] + b[e];
+    if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_lut(rbf(v[e]), g_gelu_table8);
+    }
+    if constexpr (EPI == MJV_EPI_BIAS_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if constexpr (EPI == MJV_EPI_SCALE_RES) {
+      float sc[8], rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (live) unpack8(*(const u32x4*)(p.res + (long)(m0 + ml) * p.ldr + n), rs);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rbf(v[e]);
+      if (p.scale && live) {
+        unpack8(*(const u32x4*)(p.scale + n), sc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * sc[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rs[e];
+    }
+  }
+  const u32x4 val = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+  if constexpr (OUT8) {
+    unsigned m = mx8_amax8(val);
+    m = max(m, (unsigned)__shfl_xor((int)m, 16, 64));
+    m = max(m, (unsigned)__shfl_xor((int)m, 32, 64));
+    const unsigned sb = mx8_scale_byte(m);
+    const u32x2 q = mx8_cvt8(val, mx8_scale_f32(sb));
+    if (!live) return;
+    *(u32x2*)((uint8_t*)p.C + (long)(m0 + ml) * p.ldc + n) = q;
+    if ((lane >> 4) == 0) p.Cs[mx8_scale_offset(m0 + ml, n, p.c_groups)] = (uint8_t)sb;
+  } else {
+    if (!live) return;
+    *(u32x4*)((u16*)p.C + (long)(m0 + ml) * p.ldc + n) = val;
+  }
+}
+
 template <int EPI, bool OUT8>
 int launch8(Gemm8Args a, hipStream_t s) {
   static std::atomic<unsigned long long> attr_done{0};
@@ -457,6 +571,18 @@ int launch8(Gemm8Args a, hipStream_t s) {
   }
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + 255) / 256;
+  if (a.split > 1) {
+    static std::atomic<unsigned long long> attr_split{0};
+    if (!(attr_split.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute((const void*)gemm256f8_kernel<MJV_EPI_BIAS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      attr_split.fetch_or(bit, std::memory_order_release);
+    }
+    const int tiles = a.tiles_m * a.tiles_n;
+    constexpr int CB = (EPI == MJV_EPI_SILU_MUL) ? 1 : 2;
+    hipLaunchKernelGGL((gemm256f8_kernel<MJV_EPI_BIAS, false, true>), dim3(tiles * a.split), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((splitk_finish256f8_kernel<EPI, OUT8>), dim3(tiles * 16 * CB), dim3(256), 0, s, a);
+    return mjv_check_launch("gemm_mxfp8 (K-sliced)");
+  }
   hipLaunchKernelGGL((gemm256f8_kernel<EPI, OUT8>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS_BYTES, s, a);
   return mjv_check_launch("gemm_mxfp8");
 }
@@ -487,22 +613,73 @@ int mjv_gemm_mxfp8_dispatch(const mjv_gemm_desc* d, void* stream) {
   Gemm8Args a;
   a.A = (const uint8_t*)d->A; a.lda = d->lda; a.W = (const uint8_t*)d->W; a.ldw = d->ldw;
   a.As = d->a_scales; a.a_groups = (d->M + 63) / 64; a.Ws = d->w_scales; a.w_groups = (d->N + 63) / 64;
+  a.a_grp_max = a.a_groups - 1;
   a.C = d->C; a.ldc = d->ldc; a.Cs = d->c_scales; a.c_groups = (d->M + 63) / 64;
   a.M = d->M; a.N = d->N; a.K = d->K;
   a.bias = d->bias; a.scale = d->scale; a.res = d->res; a.ldr = d->ldr;
   a.tiles_m = a.tiles_n = 0;
+  a.ws = nullptr; a.split = 1;
   a.gm = d->K <= 2048 ? 5 : (d->K >= 16384 || d->N >= 8192) ? 4 : 8;   // (gemm.hip pick_gm by K BYTES per row)
   a.nt_store = ((double)d->M * nout * (out8 ? 1.0 : 2.0) >= 32.0 * 1024 * 1024) ? 1 : 0;   // (gemm.hip: streaming stores for large outputs)
   hipStream_t s = (hipStream_t)stream;
   static const char* const tags[] = {"gemm256f8_bias", "gemm256f8_bias_gelu", "gemm256f8_bias_relu", "gemm256f8_scale_res", "gemm256f8_silu_mul"};
+  static const char* const tags_s[] = {"gemm256f8s_bias", "gemm256f8s_bias_gelu", "gemm256f8s_bias_relu", "gemm256f8s_scale_res", "gemm256f8s_silu_mul"};
   const double flops = 2.0 * d->M * (double)d->N * d->K;
   const double bytes = 1.03 * ((double)d->M * d->K + (double)d->N * d->K) + (out8 ? 1.03 : 2.0) * (double)d->M * nout;
-  MjvProfScope ps(tags[d->epilogue], s, flops, bytes);
-  switch (d->epilogue) {
-    case MJV_EPI_BIAS: return out8 ? launch8<MJV_EPI_BIAS, true>(a, s) : launch8<MJV_EPI_BIAS, false>(a, s);
-    case MJV_EPI_BIAS_GELU: return out8 ? launch8<MJV_EPI_BIAS_GELU, true>(a, s) : launch8<MJV_EPI_BIAS_GELU, false>(a, s);
-    case MJV_EPI_BIAS_RELU: return out8 ? launch8<MJV_EPI_BIAS_RELU, true>(a, s) : launch8<MJV_EPI_BIAS_RELU, false>(a, s);
-    case MJV_EPI_SCALE_RES: return launch8<MJV_EPI_SCALE_RES, false>(a, s);
-    default: return out8 ? launch8<MJV_EPI_SILU_MUL, true>(a, s) : launch8<MJV_EPI_SILU_MUL, false>(a, s);
+  auto run = [&](const Gemm8Args& g, double frac) -> int {
+    MjvProfScope ps(g.split > 1 ? tags_s[d->epilogue] : tags[d->epilogue], s, flops * frac, bytes * frac);
+    switch (d->epilogue) {
+      case MJV_EPI_BIAS: return out8 ? launch8<MJV_EPI_BIAS, true>(g, s) : launch8<MJV_EPI_BIAS, false>(g, s);
+      case MJV_EPI_BIAS_GELU: return out8 ? launch8<MJV_EPI_BIAS_GELU, true>(g, s) : launch8<MJV_EPI_BIAS_GELU, false>(g, s);
+      case MJV_EPI_BIAS_RELU: return out8 ? launch8<MJV_EPI_BIAS_RELU, true>(g, s) : launch8<MJV_EPI_BIAS_RELU, false>(g, s);
+      case MJV_EPI_SCALE_RES: return launch8<MJV_EPI_SCALE_RES, false>(g, s);
+      default: return out8 ? launch8<MJV_EPI_SILU_MUL, true>(g, s) : launch8<MJV_EPI_SILU_MUL, false>(g, s);
+    }
+  };
+  // Wave quantisation (gemm.hip does the same for the bf16 kernels): one 256 x 256 workgroup per CU, so a launch runs in
+  // ceil(tiles / CUs) rounds and a last round that is mostly empty costs a full tile time - the 64-row tail of the vision
+  // tower's 65 600 rows is a 17th round of 16 tiles after fc1's 16 full ones, w2's 552 tiles are 2.16 rounds.  With a
+  // workspace, the m-tile rows of an under-filled last round are peeled off and run K-SLICED over all CUs (fp32 slices
+  // through the workspace, summed in slice order by splitk_finish256f8_kernel: deterministic); an under-filled launch as a
+  // whole (few rows: one video per forward) is sliced the same way.  Rows are independent and 64-row scale groups stay whole
+  // (m_main % 256 == 0): results differ from the unsliced launch by fp32 re-association only.
+  const int cus = mjv_device_cus();
+  const int tn = (d->N + 255) / 256, tmx = (d->M + 255) / 256;
+  const int tiles = tn * tmx, nk = d->K / BK;
+  auto plan_split = [&](Gemm8Args& g) {
+    if (!d->workspace) return;
+    const int t = ((g.M + 255) / 256) * tn;
+    int sp = cus / t;
+    if (sp > nk / 2) sp = nk / 2;            // at least two K-tiles per slice (the pipeline's prologue fills two)
+    if (sp > 32) sp = 32;
+    if (sp < 2 || (long)t * sp * 262144L > d->workspace_bytes) return;
+    g.split = sp;
+    g.ws = (float*)d->workspace;
+  };
+  int m_main = d->M;
+  if (d->workspace && d->tile == 0) {
+    const int rem = tiles % cus;
+    const int rows_main_tiles = (tiles - rem) / tn;   // whole m-tile rows inside the full rounds
+    if (tiles > cus && rem > 0 && rem * 2 <= cus && rows_main_tiles > 0 && rows_main_tiles * 256 < d->M) m_main = rows_main_tiles * 256;
   }
+  if (m_main == d->M) {
+    if (tiles * 2 <= cus && d->tile == 0) plan_split(a);
+    return run(a, 1.0);
+  }
+  Gemm8Args head = a;
+  head.M = m_main;
+  int rc = run(head, (double)m_main / d->M);
+  if (rc) return rc;
+  // tail rows [m_main, M): every row-indexed pointer moves down m_main rows (m_main / 64 whole scale groups; the group COUNTS,
+  // which are the scale buffers' strides, stay those of the whole matrix)
+  Gemm8Args tail = a;
+  tail.M = d->M - m_main;
+  tail.A = a.A + (long)m_main * a.lda;
+  tail.As = a.As + (long)(m_main / 64) * 256;
+  tail.a_grp_max = a.a_groups - 1 - m_main / 64;
+  tail.C = out8 ? (void*)((uint8_t*)a.C + (long)m_main * a.ldc) : (void*)((u16*)a.C + (long)m_main * a.ldc);
+  if (a.Cs) tail.Cs = a.Cs + (long)(m_main / 64) * 256;
+  if (a.res) tail.res = a.res + (long)m_main * a.ldr;
+  plan_split(tail);
+  return run(tail, (double)tail.M / d->M);
 }

@@ -344,6 +344,7 @@ class InternVLChatRewardModeling(nn.Module):
         # MEASUREMENT ONLY (tools/fp8_attn_side_study.py; never set by the product): with ffn_format "mxfp8", also run the four
         # attention-side Linears (qkv / proj, wqkv / wo) on MXFP8 operands through UNFUSED launches (standalone quantiser, standalone
         # RoPE) - the numerics an all-Linear fp8 path would have, to decide whether its fused kernels are worth writing
+        # (True = all four; or a set of names out of {"qkv", "proj", "wqkv", "wo"}: the per-Linear sensitivity study of round 5)
         self._exp_fp8_attn_side = False
         # The reference ships two attention numerics.  "flash" (default since round 4): fp32 softmax on UNROUNDED scores - its
         # flash-attention path (modeling_intern_vit.py:229-244, modeling_internlm2.py:437-561), the one it runs on a GPU;
@@ -413,9 +414,16 @@ class InternVLChatRewardModeling(nn.Module):
         self.ffn_format = fmt
         return self
 
+    def _exp8_set(self) -> frozenset:
+        """the attention-side Linears the measurement flag ``_exp_fp8_attn_side`` puts on MXFP8 operands (empty in the product)"""
+        f = self._exp_fp8_attn_side
+        if not f or self.ffn_format != "mxfp8" or self.norm_fusion:
+            return frozenset()
+        return frozenset(("qkv", "proj", "wqkv", "wo")) if f is True else frozenset(f)
+
     def _signature(self):
         ps = list(self.parameters())
-        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps) + (self.ffn_format, bool(self.norm_fusion), bool(self._exp_fp8_attn_side))
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps) + (self.ffn_format, bool(self.norm_fusion), self._exp8_set())
 
     def _prepare(self, device):
         """One-time weight layout conversion (redone if any parameter storage/version changed):
@@ -474,7 +482,7 @@ class InternVLChatRewardModeling(nn.Module):
             d["fc2_8"] = [ops.quantize_mxfp8(l.mlp.fc2.weight) for l in self.model.vision_model.encoder.layers]
             d["w13_8"] = [ops.quantize_mxfp8(w) for w in w13]
             d["w2_8"] = [ops.quantize_mxfp8(l.feed_forward.w2.weight) for l in self.model.language_model.model.layers]
-            if self._exp_fp8_attn_side:
+            if self._exp8_set():
                 d["qkv_8"] = [ops.quantize_mxfp8(l.attn.qkv.weight) for l in self.model.vision_model.encoder.layers]
                 d["proj_8"] = [ops.quantize_mxfp8(l.attn.proj.weight) for l in self.model.vision_model.encoder.layers]
                 d["wqkv_8"] = [ops.quantize_mxfp8(l.attention.wqkv.weight) for l in self.model.language_model.model.layers]
@@ -765,7 +773,7 @@ class InternVLChatRewardModeling(nn.Module):
         dim, H = vc.hidden_size, vc.num_attention_heads
         scale = (dim // H) ** -0.5
         fold = self._derived["vit_fold"][li] if self.norm_fusion else None
-        exp8 = self._exp_fp8_attn_side and self.ffn_format == "mxfp8" and fold is None
+        e8 = self._exp8_set()
         if fold is not None:
             rows, dev = x.shape[0], x.device
             rstd = self._buf("vit_rstd", 1, ops.padded_rows(rows), dev, dtype=torch.float32).view(-1)
@@ -773,7 +781,7 @@ class InternVLChatRewardModeling(nn.Module):
             ops.row_stats(x, rstd, mrs, vc.layer_norm_eps)
             wq, cq, bq = fold["qkv"]
             ops.gemm(x, wq, qkv, EPI_BIAS, folded_norm=(rstd, mrs, cq, bq))
-        elif exp8:
+        elif "qkv" in e8:
             h8a = self._buf8("vit_h8a", x.shape[0], dim, x.device)
             ops.layernorm_mxfp8(x, layer.norm1.weight, layer.norm1.bias, h8a, vc.layer_norm_eps)
             ops.gemm(h8a, self._derived["qkv_8"][li], qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
@@ -782,7 +790,7 @@ class InternVLChatRewardModeling(nn.Module):
             ops.gemm(h, layer.attn.qkv.weight, qkv, EPI_BIAS, bias=layer.attn.qkv.bias)
         ops.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], h, cu, T, H, 1, 64, False, scale,
                       2 if self.attention_scores == "flash" else 0)
-        if exp8:
+        if "proj" in e8:
             a8 = ops.quantize_mxfp8(h, out=self._buf8("vit_a8", x.shape[0], dim, x.device))
             ops.gemm(a8, self._derived["proj_8"][li], x, EPI_SCALE_RES, bias=layer.attn.proj.bias, scale=layer.ls1, res=x)
         else:
@@ -879,7 +887,8 @@ class InternVLChatRewardModeling(nn.Module):
             if only_layer is not None and li != only_layer:   # (run_llm_layer: one layer on given rows)
                 continue
             lfold = d["llm_fold"][li] if self.norm_fusion else None
-            exp8 = self._exp_fp8_attn_side and self.ffn_format == "mxfp8" and lfold is None
+            e8 = self._exp8_set()
+            exp8 = bool(e8)
             trim_here = li == last and sel_rows is not None and self.debug_probes is None and only_layer is None
             pk = prefix["k"][li] if prefix is not None else None
             if trim_here and tail is not None and lfold is None and not exp8:
@@ -918,7 +927,7 @@ class InternVLChatRewardModeling(nn.Module):
                 rstd = self._buf("llm_rstd", 1, ops.padded_rows(n), dev, dtype=torch.float32).view(-1)
                 ops.row_stats(x, rstd, None, lc.rms_norm_eps)
                 ops.gemm(x, lfold["wqkv"], qkv, EPI_ROPE_QKV, rope=(cos, sin, positions, q, k, G), folded_norm=(rstd,))
-            elif exp8:
+            elif "wqkv" in e8:
                 h8a = self._buf8("llm_h8a", n, hdim, dev)
                 ops.rmsnorm_mxfp8(x, layer.attention_norm.weight, h8a, lc.rms_norm_eps)
                 ops.gemm(h8a, d["wqkv_8"][li], qkv, EPI_BIAS)
@@ -941,13 +950,13 @@ class InternVLChatRewardModeling(nn.Module):
                 act_s = self._buf("llm_act_sel", ns, ff, dev)
                 ops.embed_gather(sel_rows, hn, att_s, -1)     # row gathers (table = activation rows)
                 ops.embed_gather(sel_rows, x, x_s, -1)
-                if exp8:
+                if "wo" in e8:
                     ops.gemm(ops.quantize_mxfp8(att_s), d["wo_8"][li], x_s, EPI_SCALE_RES, res=x_s)
                 else:
                     ops.gemm(att_s, layer.attention.wo.weight, x_s, EPI_SCALE_RES, res=x_s)
                 self._llm_ffn(d, li, layer, x_s, hn_s, act_s, "sel")
                 return x_s
-            if exp8:
+            if "wo" in e8:
                 ops.gemm(ops.quantize_mxfp8(hn, out=self._buf8("llm_a8a", n, hdim, dev)), d["wo_8"][li], x, EPI_SCALE_RES, res=x)
             else:
                 ops.gemm(hn, layer.attention.wo.weight, x, EPI_SCALE_RES, res=x)
@@ -996,10 +1005,10 @@ class InternVLChatRewardModeling(nn.Module):
         hdim = lc.hidden_size
         # what the cached prefix rows depend on besides their ids: the weights (as _prepare tracks them), the rotary base
         # (dynamic NTK may have replaced it), every numerics setting, and which buffer the last layer's values live in
-        tail_form = bool(trimmed and self.trim_last_layer and not self.norm_fusion and not self._exp_fp8_attn_side)
+        tail_form = bool(trimmed and self.trim_last_layer and not self.norm_fusion and not self._exp8_set())
         self._rope_tables(int(input_ids.shape[1]), dev)   # (advances the rotary state exactly as the tower will see it)
         settings = (self._derived_sig, self._rope_state["base"], self.attention_scores, self.ffn_format, bool(self.norm_fusion),
-                    bool(self._exp_fp8_attn_side), bool(self.use_gemm_workspace), tail_form, str(dev))
+                    self._exp8_set(), bool(self.use_gemm_workspace), tail_form, str(dev))
         use_prefix = bool(self.prefix_cache and trimmed)
 
         def lookup(prefix_ids: np.ndarray) -> bool:

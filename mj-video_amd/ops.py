@@ -112,7 +112,7 @@ def set_gemm_workspace(ws: Optional[torch.Tensor]) -> None:
     _tls.gemm_ws = ws
 
 
-def _gemm_mxfp8(a: MX8, w: MX8, out, epilogue: int, bias, scale, res, M: Optional[int]):
+def _gemm_mxfp8(a: MX8, w: MX8, out, epilogue: int, bias, scale, res, M: Optional[int], workspace=None, tile=None):
     """MXFP8 operands (include/mjv.h, ABI 5): ``out`` a bf16 tensor or an ``MX8`` (the epilogue's result block-quantised)."""
     assert isinstance(w, MX8), "MXFP8 activations need MXFP8 weights"
     _chk_bf16(bias, scale, res)
@@ -137,6 +137,13 @@ def _gemm_mxfp8(a: MX8, w: MX8, out, epilogue: int, bias, scale, res, M: Optiona
     d.epilogue = epilogue
     d.bias, d.scale = _p(bias), _p(scale)
     d.res, d.ldr = _p(res), (_row_stride(res) if res is not None else 0)
+    # (the split-K scratch: peeled tail rows / under-filled launches run K-sliced; a forced tile = the one unsliced launch)
+    ws = workspace if workspace is not None else _tls.gemm_ws
+    if ws is not None and ws.device == dev:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    d.tile = _tls.tile if tile is None else tile
+    if d.tile not in (0, 256):
+        d.tile = 256    # (one tile kernel exists for MXFP8 operands: the parity tests' tile sweep maps onto it)
     with torch.cuda.device(dev):
         check(load_library().mjv_gemm_bf16(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "mjv_gemm_bf16(mxfp8)")
     return out
@@ -158,7 +165,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     ``padded_rows(N)``)."""
     if isinstance(a, MX8):
         assert res_mod == 0 and out_group == 0 and out_rows is None and rope is None, "MXFP8 GEMMs write plain rows"
-        return _gemm_mxfp8(a, w, out, epilogue, bias, scale, res, M)
+        return _gemm_mxfp8(a, w, out, epilogue, bias, scale, res, M, workspace, tile)
     _chk_bf16(a, w, out, bias, scale, res)
     lib = load_library()
     d = GemmDesc()

@@ -137,6 +137,66 @@ def test_gemm_mxfp8_exact_integers(cuda, M, N, K):
     assert torch.equal(out.cpu(), ref), f"{(out.cpu() != ref).sum().item()} of {ref.numel()} differ"
 
 
+@pytest.mark.parametrize("M,N,K", [(2112, 8192, 1024),    # 9 x 32 tiles on 256 CUs: a 64-row tail peeled off and sliced 4 x
+                                   (2304 + 80, 7168, 2048),  # 10 x 28 = 280 tiles: the last m-tile (80 rows) peeled, sliced 8 x
+                                   (200, 512, 4096),         # under-filled as a whole (2 tiles): sliced 16 x
+                                   (77, 1024, 256)])         # 4 tiles, 2 K-tiles: too short to slice - the plain launch
+@pytest.mark.parametrize("epi", ["bias", "gelu", "scale_res", "silu"])
+@pytest.mark.parametrize("out8", [False, True])
+def test_gemm_mxfp8_sliced_tails_equal_the_unsliced_launch(cuda, M, N, K, epi, out8):
+    """round 5: with a workspace, the m-tile rows of an under-filled last round (and under-filled launches as a whole) run
+    K-sliced and are finished by splitk_finish256f8_kernel - its own epilogue code, its own block quantiser.  On small-integer
+    operands every partial sum is exact, so the sliced result must equal the unsliced launch (no workspace) BIT FOR BIT: bf16
+    outputs, MXFP8 elements and scale records, every epilogue."""
+    from mj_video_amd import ops
+    if out8 and epi == "scale_res":
+        pytest.skip("the residual epilogue has no MXFP8 output")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-8, 9, (M, K), generator=g).float()
+    w = torch.randint(-7, 8, (N, K), generator=g).float()
+    a = a * torch.exp2(torch.randint(-1, 2, (M, K // 32), generator=g).float()).repeat_interleave(32, dim=1)
+    w = w * torch.exp2(torch.randint(-1, 2, (N, K // 32), generator=g).float()).repeat_interleave(32, dim=1)
+    # keep the sums small enough for GELU / SiLU to see their interesting range: scale the weights down by a power of two
+    w = w * 2.0 ** -8
+    a8, w8 = ops.quantize_mxfp8(a.to(BF).to(cuda)), ops.quantize_mxfp8(w.to(BF).to(cuda))
+    e = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "scale_res": ops.EPI_SCALE_RES, "silu": ops.EPI_SILU_MUL}[epi]
+    nout = N // 2 if epi == "silu" else N
+    bias = None if epi == "silu" else (torch.randint(-4, 5, (N,), generator=g).float() * 0.25).to(BF).to(cuda)
+    scale = (torch.randint(1, 4, (N,), generator=g).float() * 0.5).to(BF).to(cuda) if epi == "scale_res" else None
+    res = torch.randint(-8, 9, (M, N), generator=g).float().to(BF).to(cuda) if epi == "scale_res" else None
+    ws = torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=cuda)
+
+    def run(workspace):
+        out = ops.MX8.empty(M, nout, cuda) if out8 else torch.full((M, nout), float("nan"), dtype=BF, device=cuda)
+        if out8:
+            out.data.fill_(0x7F)
+            out.scales.zero_()
+        ops.gemm(a8, w8, out, e, bias=bias, scale=scale, res=(res.clone() if res is not None else None), workspace=workspace, tile=0)
+        return out
+
+    ops.prof_filter(None); ops.prof_reset(); ops.prof_enable(True)
+    try:
+        sliced = run(ws)
+        torch.cuda.synchronize()
+    finally:
+        ops.prof_enable(False)
+    tags = ops.prof_results()
+    ops.prof_reset()
+    plain = run(None)
+    torch.cuda.synchronize()
+    if (M, N, K) != (77, 1024, 256):
+        assert any(t.startswith("gemm256f8s_") for t in tags), tags.keys()    # the sliced kernels really ran
+    else:
+        assert not any(t.startswith("gemm256f8s_") for t in tags), tags.keys()
+    if out8:
+        assert torch.equal(sliced.data, plain.data), int((sliced.data != plain.data).sum())
+        assert torch.equal(sliced.scales, plain.scales), int((sliced.scales != plain.scales).sum())
+        assert not (plain.data == 0x7F).all(dim=1).any()
+    else:
+        assert torch.isfinite(plain.float()).all()
+        assert torch.equal(sliced, plain), int((sliced != plain).sum())
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 384, 128), (1025, 3072, 1024), (77, 512, 256), (640, 1024, 4096)])
 def test_gemm_mxfp8_bias_random(cuda, M, N, K):
     from mj_video_amd import ops
@@ -402,16 +462,22 @@ def test_model_mxfp8_against_fp8_oracle_c1_dims(cuda):
     print(f"score: hip8 {out8.score.item():+.4f} oracle8 {ref8['score'].item():+.4f} | hip16 {out16.score.item():+.4f} oracle16 {ref16['score'].item():+.4f}")
     # End to end the statement is statistical, as for the bf16 path (DESIGN 2 "how chaotic the path is"): after 48 layers the
     # per-layer disagreement of two fp8 implementations (single-layer test above: 0.5 % / 1.1 %, about a quarter of the layer's
-    # fp8-vs-bf16 gap) has compounded to about two thirds of the compounded gap (measured 12.3 % against 18.5 %; the bf16 path:
-    # 2.3 %).  Held here: finite, closer to the fp8 oracle than the bf16 oracle is, and within 8 x the bf16 path's own distance;
-    # the single-layer test carries the parity claim, the engineered rank set the end-to-end one (against the REFERENCE).
+    # fp8-vs-bf16 gap) has compounded to about two thirds of the compounded gap (measured 12.3 % / 13.3 % against 18.5 % / 19.7 %;
+    # the bf16 path: 2.3 % / 2.5 %).  The bound is what the single-layer test implies: its per-layer bound
+    # (4 x the bf16 layer distance + 0.3 % = 1.0 % / 1.5 %) summed in quadrature over 24 + 24 layers is 8.7 %, times the
+    # amplification the bf16 path shows between its own layer distances and its end-to-end one (2.3 % from 1.67 %: 1.38 x) = 12 %,
+    # i.e. 5.2 x the bf16 end-to-end distance measured in this very test -> held to 6 x (round 4 accepted 8 x), to 0.75 of the
+    # fp8-vs-bf16 gap (round 4: 1.0), and the score to 0.3 of the oracles' own fp8-vs-bf16 score gap (measured 0.20; round 4
+    # accepted max(gap, 0.25), i.e. any score between the two oracles).
     for k in r8:
-        assert r8[k] < gap[k], (k, r8[k], gap[k])
-        assert r8[k] <= 8.0 * r16[k], (k, r8[k], r16[k])
+        assert r8[k] <= 0.75 * gap[k], (k, r8[k], gap[k])
+        assert r8[k] <= 6.0 * r16[k], (k, r8[k], r16[k])
     for k in ("score", "aspect_scores", "rewards", "aspect_gating_output"):
         assert torch.isfinite(getattr(out8, k).float()).all(), k
     d_score = abs(out8.score.item() - ref8["score"].item())
-    assert d_score <= max(abs(ref8["score"].item() - ref16["score"].item()), 0.25), (d_score,)
+    gap_score = abs(ref8["score"].item() - ref16["score"].item())
+    print(f"score: |hip8 - oracle8| {d_score:.4f} = {d_score / gap_score:.3f} of the oracles' fp8-vs-bf16 gap {gap_score:.4f}")
+    assert d_score <= max(0.3 * gap_score, 0.05), (d_score, gap_score)
 
 
 def _rank_case_engineered_mxfp8(cuda, name, pairs_per_forward, max_noise_ratio, min_agree, min_rho):

@@ -487,6 +487,8 @@ def test_attention_rising_scores_exercise_the_offset_raise(cuda, attn_variant, D
     new offset exactly once.  Here the scores RISE along the keys (ramp 0.6 / 0.12 log2 units per key plus noise: a raise every
     ~30 / ~150 keys, each by a few binades, so what was accumulated before stays significant after it), or fall (-0.6: never a
     raise, the first keys dominate).  Against the fp32 reference, same bounds as test_attention."""
+    if two_wave_form_refused(cuda, attn_variant, D):
+        return
     _rising_scores_case(cuda, D, causal, L, ramp, 1 if causal else 0)
 
 
