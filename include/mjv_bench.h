@@ -35,6 +35,12 @@ int mjv_bench_attention_set(int32_t variant);
 int mjv_bench_rmsnorm_prestat(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy, const mjv_bf16* w,
                               const float* partials, int32_t rows, int32_t dim, float eps, void* stream);
 
+/* The elementwise pass an UN-fused Linear would owe after a plain vendor GEMM (tools/fused_vs_unfused.py): same operations and
+ * rounding points as the fused epilogues, HBM-bound.  kind 1: y = gelu(bf16(x + bias)); kind 3: y = res + bf16(bf16(x + bias)
+ * * scale) (scale / bias may be NULL). */
+int mjv_bench_epilogue_pass(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy, const mjv_bf16* bias, const mjv_bf16* scale,
+                            const mjv_bf16* res, int64_t ldr, int32_t rows, int32_t cols, int32_t kind, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,7 @@ BENCH_SYMBOLS = {
     "mjv_bench_gemm_stamp_buffer": (C.c_int, [_VP]),
     "mjv_bench_attention_set": (C.c_int, [_I32]),
     "mjv_bench_rmsnorm_prestat": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, C.c_float, _VP]),
+    "mjv_bench_epilogue_pass": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _VP]),
 }
 BENCH_LIB_PATH = os.path.join(_PKG_DIR, "libmjv_hip_bench.so")
 

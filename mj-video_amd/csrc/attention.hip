@@ -849,6 +849,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   // rare path: raise the offset of sub-block sb to cover unit scores S, rescale its state, recompute the unit's P
   auto redo = [&](const f32x16& S, auto sbc, float& psum, unsigned (&pw)[8]) __attribute__((always_inline)) {
     constexpr int sb = decltype(sbc)::value;
+#ifdef MJV_ATTN_STAMPS
+    st_acc[10] += 1;   // (diagnostic build: units that took the offset-raise path, per wave - tools/stress_stats.py)
+#endif
     float mx = S[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);

@@ -1,6 +1,7 @@
 // HBM-bound row kernels: LayerNorm (+pixel-shuffle gather), RMSNorm (+row gather), RoPE/GQA split,
 // patchify (im2col), CLS rows, token-embedding gather.  One 64-lane wave per row, 16-byte accesses.
 #include "mjv_common.h"
+#include <algorithm>
 #include "mx8.h"
 
 namespace {
@@ -372,6 +373,71 @@ extern "C" int mjv_bench_rmsnorm_prestat(const mjv_bf16* x, int64_t ldx, mjv_bf1
   hipLaunchKernelGGL((rmsnorm_kernel<4, 8>), grid, dim3(256), 0, s, x, (long)ldx, y, (long)ldy, w, (const int*)nullptr, rows, dim, eps,
                      partials);
   return mjv_check_launch("rmsnorm_prestat");
+}
+
+// The elementwise pass an UN-fused Linear would owe (tools/fused_vs_unfused.py): y = epilogue(x) over a
+// [rows][cols] bf16 matrix, the same operations and rounding points as the GEMM epilogues, written as the cheapest correct
+// HBM-bound kernel - 16-byte loads and stores, a grid of one wave's worth of rows per workgroup pass, the GELU table in LDS.
+//   kind 1: y = gelu(bf16(x + bias))              (fc1)
+//   kind 3: y = res + bf16(bf16(x + bias) * scale)   (proj / fc2; scale NULL: y = res + bf16(x + bias); bias NULL: wo / w2)
+#include "gelu_table.h"
+namespace {
+__device__ const u16 g_gelu_table_pass[MJV_GELU_TABLE_LEN] = MJV_GELU_TABLE_INIT;
+template <int KIND>
+__global__ __launch_bounds__(256) void epilogue_pass_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ y, long ldy,
+                                                            const u16* __restrict__ bias, const u16* __restrict__ scale,
+                                                            const u16* __restrict__ res, long ldr, int rows, int cols) {
+  __shared__ u16 tab[KIND == 1 ? MJV_GELU_TABLE_LEN : 8];
+  if constexpr (KIND == 1) {
+    for (int i = threadIdx.x; i < MJV_GELU_TABLE_LEN / 8; i += 256) ((u32x4*)tab)[i] = ((const u32x4*)g_gelu_table_pass)[i];
+    __syncthreads();
+  }
+  const int cpr = cols / 8;                       // 16-byte chunks per row
+  const long total = (long)rows * cpr;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < total; c += (long)gridDim.x * 256) {
+    const long row = c / cpr;
+    const int col = (int)(c - row * cpr) * 8;
+    float v[8], b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unpack8(__builtin_nontemporal_load((const u32x4*)(x + row * ldx + col)), v);
+    if (bias) unpack8(*(const u32x4*)(bias + col), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + b[e]);
+    if constexpr (KIND == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned u = __float_as_uint(v[e]);
+        const unsigned mag = (u >> 16) & 0x7fffu, rel = mag - MJV_GELU_LO;
+        const bool in_tab = rel < (unsigned)MJV_GELU_R;
+        const unsigned t = tab[in_tab ? rel + (u >> 31) * MJV_GELU_NEG_OFF : 0u];
+        const unsigned other = mag < MJV_GELU_LO ? __float_as_uint(0.5f * v[e]) : gelu_beyond_table(u, mag);
+        v[e] = __uint_as_float(in_tab ? (t << 16) : other);
+      }
+    } else {
+      float r[8], sc[8];
+      unpack8(__builtin_nontemporal_load((const u32x4*)(res + row * ldr + col)), r);
+      if (scale) {
+        unpack8(*(const u32x4*)(scale + col), sc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] * sc[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    __builtin_nontemporal_store(pack8(v), (u32x4*)(y + row * ldy + col));
+  }
+}
+}  // namespace
+extern "C" int mjv_bench_epilogue_pass(const mjv_bf16* x, int64_t ldx, mjv_bf16* y, int64_t ldy, const mjv_bf16* bias,
+                                       const mjv_bf16* scale, const mjv_bf16* res, int64_t ldr, int32_t rows, int32_t cols,
+                                       int32_t kind, void* stream) {
+  MJV_REQUIRE(x && y && rows > 0 && cols > 0 && cols % 8 == 0 && (kind == 1 || (kind == 3 && res)), "epilogue_pass: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)rows * (cols / 8);
+  const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);   // 16 workgroups per CU, grid-stride
+  MjvProfScope ps(kind == 1 ? "bench_pass_bias_gelu" : "bench_pass_scale_res", s, 0, (kind == 1 ? 4.0 : 6.0) * rows * (double)cols);
+  if (kind == 1) hipLaunchKernelGGL(epilogue_pass_kernel<1>, dim3(blocks), dim3(256), 0, s, x, (long)ldx, y, (long)ldy, bias, scale, res, (long)ldr, rows, cols);
+  else hipLaunchKernelGGL(epilogue_pass_kernel<3>, dim3(blocks), dim3(256), 0, s, x, (long)ldx, y, (long)ldy, bias, scale, res, (long)ldr, rows, cols);
+  return mjv_check_launch("epilogue_pass");
 }
 #endif
 

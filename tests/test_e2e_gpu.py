@@ -599,7 +599,10 @@ def test_prefix_cache_is_invisible_and_invalidates(cuda, fmt):
     for f in ("hidden_state", "prompt_embedding"):
         e = rel_l2(getattr(sliced, f).float().cpu().numpy(), getattr(plain, f).float().cpu().numpy())
         print(f"prefix cache on vs off, K-slicing on, {fmt}, {f}: relative L2 {e:.4f}")
-        assert e < 0.045, (f, e)
+        # bf16: as above.  mxfp8: a re-associated sum moves some FFN inputs across an e4m3 rounding boundary (2^-3 of the element, not
+        # 2^-8) - two fp8 evaluations that slice K differently (the row count decides which tail rows run K-sliced) differ like two
+        # fp8 implementations do (test_fp8_gpu.py: 12 % end to end at these dims; measured here 8.6 %)
+        assert e < (0.045 if fmt == "bf16" else 0.15), (f, e)
 
 
 def test_k_sliced_path_is_no_further_from_fp32(cuda):
