@@ -864,7 +864,8 @@ class InternVLChatRewardModeling(nn.Module):
         (moe_reward.py:211,229,243) - and the [len(sel_rows), hidden] result is returned instead of ``x``.
         ``tail`` (with ``sel_rows``; ``trim_last_layer``) = (tail_rows, tail_pos, cu_tail, max_tail, sel_in_tail): the last
         layer computes queries only for those rows.  ``prefix`` = the cached keys / values of the prompt prefix the packed rows
-        leave out (``prefix_cache``); ``snapshot`` = (P, store): keep rows [0, P) of every layer's K / V in ``store``."""
+        leave out (``prefix_cache``); ``snapshot`` (the prefix-only pass of ``_build_prefix``) = (P, store): keep rows [0, P) of
+        every layer's K / V in ``store``."""
         dev = x.device
         lc = self.config.llm_config
         lm = self.model.language_model.model
@@ -899,9 +900,6 @@ class InternVLChatRewardModeling(nn.Module):
                 kv = self._buf("llm_kv_last", n, 2 * KV * hd, dev)
                 ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
                 ops.gemm(hn, d["wkv_last"], kv, EPI_ROPE_QKV, rope=(cos, sin, positions, None, k, 0))
-                if snapshot is not None:
-                    snapshot[1]["k"].append(k[:snapshot[0]].clone())
-                    snapshot[1]["v_last"] = kv[:snapshot[0]].clone()
                 hn_t = self._buf("llm_hn_tail", nt, hdim, dev)
                 qkv_t = self._buf("llm_qkv_tail", nt, (H + 2 * KV) * hd, dev)
                 q_t = self._buf("llm_q_tail", nt, H * hd, dev)
@@ -935,7 +933,7 @@ class InternVLChatRewardModeling(nn.Module):
             else:
                 ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
                 ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_ROPE_QKV, rope=(cos, sin, positions, q, k, G))
-            if snapshot is not None:   # rows [0, P) of sample 0: the prompt prefix's keys (rotated) and values of this layer
+            if snapshot is not None:   # the prompt prefix's keys (rotated) and values of this layer
                 snapshot[1]["k"].append(k[:snapshot[0]].clone())
                 snapshot[1]["v"].append(qkv[:snapshot[0]].clone())
             ops.attention(q, k, v_view, hn, cu, max_len, H, G, hd, True, scale, mode, v_head_stride=(G + 2) * hd,
@@ -987,6 +985,31 @@ class InternVLChatRewardModeling(nn.Module):
             ops.gemm(hn, d["w13"][li], act, EPI_SILU_MUL)
         ops.gemm(act, layer.feed_forward.w2.weight, x, EPI_SCALE_RES, res=x)
 
+    def _build_prefix(self, d, prefix_ids: np.ndarray, settings, padded_len: int, dev) -> None:
+        """Fills ``self._prefix``: the language tower over the ``P`` prefix tokens alone (one short sequence, positions 0 .. P - 1;
+        P is a multiple of 64), keeping every layer's rotated keys and values.  Under the causal mask these rows are exactly
+        what any sequence that starts with those tokens computes for them - bit for bit when no GEMM slices K (a row's sums do
+        not depend on the rows around it), up to fp32 re-association otherwise."""
+        lc = self.config.llm_config
+        P = int(prefix_ids.shape[0])
+        H, KV, hd = lc.num_attention_heads, lc.num_key_value_heads, 128
+        G = H // KV
+        ids = torch.from_numpy(prefix_ids.astype(np.int32)).to(dev)
+        x = self._buf("llm_x", P, lc.hidden_size, dev)
+        ops.embed_gather(ids, self.model.language_model.model.tok_embeddings.weight, x, self.model.img_context_token_id)
+        cu = torch.tensor([0, P], dtype=torch.int32, device=dev)
+        pos = torch.arange(P, dtype=torch.int32, device=dev)
+        store = dict(k=[], v=[])
+        self._language_tower(d, x, cu, pos, P, None, padded_len=padded_len, snapshot=(P, store))
+        # the last layer's values once more in the [k | v] column layout of the trimmed last layer (wkv_last: kv head h at
+        # columns 256 h + 128 ...), copied from their wqkv columns ((G + 2) 128 h + (G + 1) 128 ...): same sums, same values
+        v_last = torch.zeros(P, 2 * KV * hd, dtype=BF16, device=dev)
+        v_last.view(P, KV, 2, hd)[:, :, 1] = store["v"][-1].view(P, KV, G + 2, hd)[:, :, G + 1]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))   # a later forward on ANOTHER stream waits for the rows to exist
+        self._prefix = dict(settings=settings, ids=prefix_ids.copy(), P=P, k=store["k"], v=store["v"], v_last=v_last, ready=ready,
+                            stream=torch.cuda.current_stream(dev).cuda_stream)
+
     # -- forward ---------------------------------------------------------------------------------
     def _forward_group(self, d, tag: str, pixel_values, host_ids, outs, lo: int, probes_ok: bool):
         """Scores the batch on the CURRENT stream of the model's device (outputs go to rows [lo, lo+B) of ``outs``).
@@ -1010,22 +1033,26 @@ class InternVLChatRewardModeling(nn.Module):
         settings = (self._derived_sig, self._rope_state["base"], self.attention_scores, self.ffn_format, bool(self.norm_fusion),
                     self._exp8_set(), bool(self.use_gemm_workspace), tail_form, str(dev))
         use_prefix = bool(self.prefix_cache and trimmed)
+        hit = []
 
         def lookup(prefix_ids: np.ndarray) -> bool:
             c = self._prefix
-            return (c is not None and c["settings"] == settings and c["ids"].shape == prefix_ids.shape
-                    and bool((c["ids"] == prefix_ids).all()))
+            hit.append(c is not None and c["settings"] == settings and c["ids"].shape == prefix_ids.shape
+                       and bool((c["ids"] == prefix_ids).all()))
+            if not hit[0]:
+                # a prefix this model holds no keys / values for (first forward, new weights, another prompt, another setting):
+                # computed once, by a pass over the prefix tokens ALONE, before this forward's tower - so that a forward's result
+                # never depends on whether the cache was warm (the same cached computation either way)
+                self._build_prefix(d, prefix_ids, settings, int(input_ids.shape[1]), dev)
+            return True
 
         info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0], lookup if use_prefix else None)  # host arrays
         B, total = info["B"], info["total"]
         prefix = self._prefix if info["skip"] else None
-        snapshot = None
-        if use_prefix and prefix is None and info["prefix_ids"] is not None:
-            # a prefix this model has no keys / values for (first forward, new weights, new prompt): computed like every other
-            # row in THIS forward, and its rows kept for the next ones
-            snapshot = (int(info["prefix_ids"].shape[0]), dict(k=[], v=[], v_last=None))
-        if prefix is not None:
+        if prefix is not None and hit[0]:
             self.prefix_cache_hits += 1
+            if prefix["stream"] != torch.cuda.current_stream(dev).cuda_stream:
+                torch.cuda.current_stream(dev).wait_event(prefix["ready"])
 
         def up(a):
             return torch.from_numpy(a).to(dev, non_blocking=True)
@@ -1041,10 +1068,7 @@ class InternVLChatRewardModeling(nn.Module):
         if self.debug_probes is not None and probes_ok:
             self.debug_probes["llm_embed"] = hidden.clone()
         last_x = self._language_tower(d, hidden, cu, positions, info["max_len"], sel_rows if trimmed else None, padded_len=info["N"],
-                                      tail=tail, prefix=prefix, snapshot=snapshot)
-        if snapshot is not None:
-            st = snapshot[1]
-            self._prefix = dict(settings=settings, ids=info["prefix_ids"].copy(), P=snapshot[0], k=st["k"], v=st["v"], v_last=st["v_last"])
+                                      tail=tail, prefix=prefix)
 
         # final RMSNorm only on the 2 rows per sample the heads read (hidden_states[-1] is post-norm, moe_reward.py:211)
         h_r, h_g = outs["hidden_state"][lo:lo + B], outs["prompt_embedding"][lo:lo + B]

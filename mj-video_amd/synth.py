@@ -245,3 +245,46 @@ def pad_batch(ids_list: List[torch.Tensor], pad_id: int = PAD_ID, length: Option
         ids[i, :k] = t.reshape(-1)
         mask[i, :k] = 1
     return ids, mask
+
+
+def stress_tensors(tensors: Dict[str, torch.Tensor], config, massive_frac: float = 0.01, massive_gain: float = 20.0,
+                   logit_sigma: float = 10.0, fc1_sigma: float = 2.0, seed: int = 0) -> Dict[str, float]:
+    """Re-scales random-init weights IN PLACE (``tensors``: checkpoint key -> tensor, e.g. ``dict(model.named_parameters())`` or a
+    state dict) so that the forward sees the statistics of a TRAINED transformer instead of the benign ones N(0, 0.02) weights
+    give (VERDICT r4 item 4; tools/stress_stats.py, tests/test_e2e_gpu.py::test_stressed_statistics_*):
+      * massive activations: ``massive_frac`` of the hidden channels carry ``massive_gain`` x the others' magnitude in the
+        residual stream's producers (rows of proj / fc2 and their biases in the vision tower, of wo / w2 in the language tower);
+      * attention logits of standard deviation ``logit_sigma`` (+-3 sigma = +-30): the q and k rows of qkv / wqkv are scaled by the
+        square root of logit_sigma / (the benign logit sigma: 0.41 in the vision tower, 0.82 in the language tower - SURVEY.md §8);
+      * fc1 pre-activations of standard deviation ``fc1_sigma`` (benign: 0.64): fc1 weight and bias scaled.
+    Returns the factors applied."""
+    vc, lc = config.vision_config, config.llm_config
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def rows(n):
+        k = max(1, int(round(massive_frac * n)))
+        return torch.randperm(n, generator=g)[:k]
+
+    vit_rows, llm_rows = rows(vc.hidden_size), rows(lc.hidden_size)
+    hd_v = vc.hidden_size // vc.num_attention_heads
+    benign_v = (vc.hidden_size * 0.02 ** 2) * hd_v ** 0.5 * hd_v ** -0.5      # sigma of q.k / sqrt(d) under N(0, 0.02) weights, unit inputs
+    hd_l = lc.hidden_size // lc.num_attention_heads
+    benign_l = (lc.hidden_size * 0.02 ** 2)
+    qk_v, qk_l = (logit_sigma / benign_v) ** 0.5, (logit_sigma / benign_l) ** 0.5
+    fc1 = fc1_sigma / (vc.hidden_size ** 0.5 * 0.02)
+    G = lc.num_attention_heads // lc.num_key_value_heads
+    for key, t in tensors.items():
+        with torch.no_grad():
+            if ".attn.proj." in key or ".mlp.fc2." in key:
+                t[vit_rows.to(t.device)] *= massive_gain
+            elif key.endswith("attention.wo.weight") or key.endswith("feed_forward.w2.weight"):
+                t[llm_rows.to(t.device)] *= massive_gain
+            elif ".attn.qkv." in key:
+                t[: 2 * vc.hidden_size] *= qk_v                       # q rows, then k rows (modeling_intern_vit.py:212-216)
+            elif key.endswith("attention.wqkv.weight"):
+                v = t.view(lc.num_key_value_heads, G + 2, hd_l, t.shape[1])
+                v[:, : G + 1] *= qk_l                                  # q heads of the group and its k head (modeling_internlm2.py:361-371)
+            elif ".mlp.fc1." in key:
+                t *= fc1
+    return dict(massive_rows_vit=int(vit_rows.numel()), massive_rows_llm=int(llm_rows.numel()), massive_gain=massive_gain,
+                qk_scale_vit=qk_v, qk_scale_llm=qk_l, fc1_scale=fc1)
