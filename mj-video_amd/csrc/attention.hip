@@ -559,9 +559,9 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 // between the MFMAs with sched_barrier (left alone the compiler issues all MFMAs first).
 //
 // The softmax is "optimistic": the running offset M of a query is an INTEGER in exp2 units (M = ceil of the rounded score in
-// log2 units at the time it was last set) and a unit does NOT compute its row max: p = exp2(s c - M) directly, and only if a
-// lane's partial row sum comes out above 2^20 (or NaN: the first tile starts from M = -inf) the unit is redone with
-// M <- max(M, ceil(unit max)).  Because M is an integer every rescale factor is an exact power of two, and bf16 rounding of P
+// log2 units at the time it was last set, + HEADROOM = 64 since round 5: see HEADROOM below) and a unit does NOT compute its row
+// max: p = exp2(s c - M) directly, and only if a lane's partial row sum comes out above 2^20 (or NaN: the first tile starts from
+// M = -inf) the unit is redone with M <- max(M, ceil(unit max) + HEADROOM).  Because M is an integer every rescale factor is an exact power of two, and bf16 rounding of P
 // commutes with it: O / l do not depend on WHEN a query's offset was raised (no rounding-level difference between the lazy and
 // the eager schedule), only on the offsets being integers.  This removes the max (16 v_max3 + exchange per unit), the exp of
 // the rescale factor and, almost always, the rescale of the O accumulators from the per-tile vector work: 4.7 -> 3.7 vector
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, (D == 64) ? 4 : 2) void attn_kernel(AttnArgs p
 // instead of one per tile).
 //
 // Sequences whose length is 1 (mod 64) - the vision tower's 1 + 32^2 tokens - would need a 17th key tile and a 9th query block
-// for ONE token.  For them (non-causal only) key 0 becomes the INITIAL STATE of the online softmax (M = ceil(s(q, k_0) c),
+// for ONE token.  For them (non-causal only) key 0 becomes the INITIAL STATE of the online softmax (M = ceil(s(q, k_0) c) + HEADROOM,
 // l = p_0, O = bf16(p_0) v_0: 32 FMAs per lane, once) and the key tiles start at key 1; the query blocks start at query 1 and
 // query 0 is run by one wave of an extra block.
 // =====================================================================================================================
@@ -581,6 +581,14 @@ template <int N, class Fn>
 MJV_DEV void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr float BIGSUM = 1048576.f;   // 2^20: a lane's partial row sum above this redoes the unit with a raised offset
+// Whenever an offset is set it is set HEADROOM binades ABOVE the largest score seen (round 5).  The probabilities are powers of
+// two smaller for it - nothing else changes: bf16 / fp32 keep their relative precision anywhere in their exponent range, the
+// normalisation divides the factor out - but the next raise now needs a score 2^(20 + 64) above the maximum that set the
+// offset instead of 2^20.  With the offset AT the maximum, trained-like logits (sigma 10: 14 binades per sigma, later maxima
+// 20 - 40 binades above the first unit's) sent 12 % of the units through the raise path and cost the kernels 6 - 9 %
+// (tools/stress_stats.py, profiles/r05_e_stress_stats.txt).  A score more than 126 - 64 = 62 binades BELOW the maximum now
+// underflows to 0: a weight below 2^-62 of the row's largest, 38 binades under what an fp32 sum resolves.
+constexpr float HEADROOM = 64.f;
 
 struct Pos { int slot, kind, unit, f; };   // kind 0 = QK^T, 1 = PV
 // MFMA stream of one key tile: slot s holds the F MFMAs of PV(s - 2) (if that unit exists), then the F of QK(s)
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
 
   if (peel && hasA && !(cls_block && wave == 1)) {
     // key 0 as the initial state.  s = q . k_0 in fp32 (this lane's 8-element groups, then the other half-lane's), rounded
-    // like every score; M = ceil(s c); p_0 = exp2(s c - M) in (1/2, 1]; l = bf16(p_0) (counted in the hi = 0 lane only: row sums
+    // like every score; M = ceil(s c) + HEADROOM; p_0 = exp2(s c - M) in (1/2, 1] 2^-64; l = bf16(p_0) (counted in the hi = 0 lane only: row sums
     // are lane-partial); O = bf16(p_0) * v_0 - what the MFMA would have accumulated for this key.
     const u16* k0p = Kg + (long)s0 * p.ldk + 8 * hi;
     const u16* v0p = Vg + (long)s0 * p.ldv;
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
       }
       dot = xhalf_sum(dot);
       const float arg = round_score<RM>(dot, p.scale) * c_exp;
-      const float m0 = ceilf(arg);
+      const float m0 = ceilf(arg) + HEADROOM;
       const float p0 = __builtin_amdgcn_exp2f(arg - m0);
       const float pb = rbf(p0);
       Mq[sb] = m0;
@@ -857,7 +865,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
     mx = xhalf_max(mx);
     const float arg = round_score<RM>(mx, p.scale) * c_exp;
-    float mn = fmaxf(Mq[sb], ceilf(arg));
+    float mn = fmaxf(Mq[sb], ceilf(arg) + HEADROOM);
     if (!(mn > -INFINITY)) mn = 0.f;                       // nothing but masked keys so far
     const float alpha = __builtin_amdgcn_exp2f(Mq[sb] - mn);   // exact power of two (0 from the initial -inf)
     lsum[sb] *= alpha;

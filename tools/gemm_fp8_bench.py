@@ -49,7 +49,7 @@ for name, M, N, K, epi, out8 in shapes:
     scale = torch.randn(N, device=dev).to(BF) if epi == ops.EPI_SCALE_RES and "vit" in name else None
     o16 = torch.empty(M, nout, device=dev, dtype=BF)
     o8 = ops.MX8.empty(M, nout, dev) if out8 else None
-    f8 = lambda: ops.gemm(a8, w8, o8 if out8 else o16, epi, bias=bias, scale=scale, res=res)          # noqa: E731
+    f8 = lambda: ops.gemm(a8, w8, o8 if out8 else o16, epi, bias=bias, scale=scale, res=res, workspace=ws)   # noqa: E731  (round 5: tails K-sliced)
     f16 = lambda: ops.gemm(a, w, o16, epi, bias=bias, scale=scale, res=res, workspace=ws)             # noqa: E731
     t8, t16 = [], []
     for rnd in range(ROUNDS):
@@ -58,3 +58,25 @@ for name, M, N, K, epi, out8 in shapes:
     fl = 2.0 * M * N * K / 1e9
     print(f"{name:28s} {M:6d} {N:6d} {K:5d} | {np.median(t8):7.3f} ms {fl / np.median(t8):6.0f} ({fl / min(t8):5.0f}) | "
           f"{np.median(t16):7.3f} ms {fl / np.median(t16):6.0f} | {np.median(t16) / np.median(t8):.2f}x", flush=True)
+
+
+# ---- round 5: where the time of fc1 + GELU -> MXFP8 goes.  The same main rows (65 536 x 4096 x 1024: 16 full
+# rounds of 256 tiles, 8 K-tiles of 128 per tile) under four epilogues, interleaved; per TILE = launch time x 256 CUs / 4096 tiles.
+print("\nfc1 (65536 x 4096 x 1024, mxfp8 operands): epilogue decomposition, ms per launch median | TFLOP/s | us per 256 x 256 tile")
+M, N, K = 65536, 4096, 1024
+a = torch.randn(M, K, device=dev).to(BF)
+w = (torch.randn(N, K, device=dev) * 0.05).to(BF)
+a8, w8 = ops.quantize_mxfp8(a), ops.quantize_mxfp8(w)
+bias = torch.randn(N, device=dev).to(BF)
+o16, o8 = torch.empty(M, N, device=dev, dtype=BF), ops.MX8.empty(M, N, dev)
+cases = [("bias -> bf16", ops.EPI_BIAS, o16), ("bias -> mxfp8", ops.EPI_BIAS, o8), ("bias + gelu -> bf16", ops.EPI_BIAS_GELU, o16),
+         ("bias + gelu -> mxfp8 (the model's)", ops.EPI_BIAS_GELU, o8)]
+ts = {c[0]: [] for c in cases}
+for rnd in range(ROUNDS):
+    for name, epi, out in cases[rnd % 4:] + cases[:rnd % 4]:
+        ts[name].append(timed(lambda: ops.gemm(a8, w8, out, epi, bias=bias)))
+fl = 2.0 * M * N * K / 1e9
+for name, _, _ in cases:
+    t = np.median(ts[name])
+    print(f"  {name:36s} {t:7.3f} ms | {fl / t:6.0f} | {t * 1e3 * 256 / 4096:6.2f}")
+print("  (the MFMA time of a tile at the 5 PFLOP/s peak: 6.9 us; at the rate the K = 8192 main loop holds, 2 600 TFLOP/s: 13.2 us)")
