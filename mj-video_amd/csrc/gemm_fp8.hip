@@ -647,7 +647,7 @@ int mjv_gemm_mxfp8_dispatch(const mjv_gemm_desc* d, void* stream) {
   const int tn = (d->N + 255) / 256, tmx = (d->M + 255) / 256;
   const int tiles = tn * tmx, nk = d->K / BK;
   auto plan_split = [&](Gemm8Args& g) {
-    if (!d->workspace) return;
+    if (!d->workspace || nk < 8) return;     // (K < 1024: two launches cost more than the idle CUs)
     const int t = ((g.M + 255) / 256) * tn;
     int sp = cus / t;
     if (sp > nk / 2) sp = nk / 2;            // at least two K-tiles per slice (the pipeline's prologue fills two)
@@ -660,7 +660,7 @@ int mjv_gemm_mxfp8_dispatch(const mjv_gemm_desc* d, void* stream) {
   if (d->workspace && d->tile == 0) {
     const int rem = tiles % cus;
     const int rows_main_tiles = (tiles - rem) / tn;   // whole m-tile rows inside the full rounds
-    if (tiles > cus && rem > 0 && rem * 2 <= cus && rows_main_tiles > 0 && rows_main_tiles * 256 < d->M) m_main = rows_main_tiles * 256;
+    if (nk >= 8 && tiles > cus && rem > 0 && rem * 2 <= cus && rows_main_tiles > 0 && rows_main_tiles * 256 < d->M) m_main = rows_main_tiles * 256;
   }
   if (m_main == d->M) {
     if (tiles * 2 <= cus && d->tile == 0) plan_split(a);

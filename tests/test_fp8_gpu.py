@@ -140,7 +140,7 @@ def test_gemm_mxfp8_exact_integers(cuda, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(2112, 8192, 1024),    # 9 x 32 tiles on 256 CUs: a 64-row tail peeled off and sliced 4 x
                                    (2304 + 80, 7168, 2048),  # 10 x 28 = 280 tiles: the last m-tile (80 rows) peeled, sliced 8 x
                                    (200, 512, 4096),         # under-filled as a whole (2 tiles): sliced 16 x
-                                   (77, 1024, 256)])         # 4 tiles, 2 K-tiles: too short to slice - the plain launch
+                                   (77, 1024, 512)])         # 4 tiles, 4 K-tiles: too short to slice - the plain launch
 @pytest.mark.parametrize("epi,out8", [("bias", False), ("bias", True), ("gelu", False), ("gelu", True), ("scale_res", False),
                                       ("silu", False), ("silu", True)])     # (the residual epilogue has no MXFP8 output)
 def test_gemm_mxfp8_sliced_tails_equal_the_unsliced_launch(cuda, M, N, K, epi, out8):
@@ -182,7 +182,7 @@ def test_gemm_mxfp8_sliced_tails_equal_the_unsliced_launch(cuda, M, N, K, epi, o
     ops.prof_reset()
     plain = run(None)
     torch.cuda.synchronize()
-    if (M, N, K) != (77, 1024, 256):
+    if (M, N, K) != (77, 1024, 512):
         assert any(t.startswith("gemm256f8s_") for t in tags), tags.keys()    # the sliced kernels really ran
     else:
         assert not any(t.startswith("gemm256f8s_") for t in tags), tags.keys()
