@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Writes KERNELS.md - the one-page state of the kernels - from a bench.py line (the per-kernel table of its profiled step and
+the `secondary` legs) plus the fixed text below.  usage: kernels_md.py profiles/rNN_x_bench_default.json [driver BENCH_rNN.json]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_line(path):
+    txt = open(path).read()
+    try:
+        j = json.loads(txt)
+        if isinstance(j, dict) and "parsed" in j:      # a driver record (BENCH_rNN.json)
+            return j["parsed"]
+    except ValueError:
+        pass
+    return json.loads([ln for ln in txt.splitlines() if ln.startswith('{"metric')][-1])
+
+
+# kernel tag -> (what it is, shapes at the headline workload, bound, peak for `frac`, the ONE reason it is not faster, DESIGN anchor)
+ROWS = [
+    ("gemm256_scale_res", "256² tile GEMM, bias·LayerScale + residual epilogue", "ViT proj 65 536×1024×1024, fc2 65 536×1024×4096; LLM wo 16 384×2048×2048, w2 16 384×2048×8192 (main rows)", "MFMA", 2500,
+     "main loop at 0.85-0.96 of what the 1.7-1.9 GHz the chip holds allows; the residual epilogue (64 residual registers, LDS round trip) is not overlapped by MFMA work: 1 workgroup per CU owns all 160 KiB", "§4 Measured r4 'the clock'; §7.1"),
+    ("gemm256_silu_mul", "256² GEMM, SiLU(w1 x)·(w3 x) epilogue, persistent form", "LLM w1∣w3 16 976×16 384×2048", "MFMA", 2500,
+     "same main loop; last round 75 % full (67 × 64 tiles = 16.75 rounds) and 5.5 × the algorithmic fabric bytes (tile order floor)", "§4 r3 'persistent'"),
+    ("gemm256_bias_gelu", "256² GEMM, bias + exact-erf GELU by table", "ViT fc1 65 536×4096×1024", "MFMA", 2500,
+     "K = 1024 is 16 K-tiles per tile, so the epilogue is ⅓ of a tile's life; 128 LDS table gathers per lane (≈ 9 LDS cycles each: random banks) + 5.5 vector instr. per element that no MFMA overlaps", "§4 r4 'GELU'; §6e item 6"),
+    ("gemm256_bias", "256² GEMM, bias epilogue, persistent form", "ViT qkv 65 536×3072×1024; projector", "MFMA", 2500,
+     "short K (16 K-tiles): prologue + epilogue ≈ 20 % of a tile even with the next tile's first K-tile prefetched under the epilogue", "§4 r3 'persistent'"),
+    ("gemm256_rope_qkv", "256² GEMM, rotary embedding + GQA de-interleave epilogue", "LLM wqkv 16 384×4096×2048 (23 layers), last layer k∣v 16 384×2048×2048", "MFMA", 2500,
+     "two dependent table fetches (position → cos / sin rows) per pass in the epilogue; no persistent form (its LDS window is the whole tile)", "§4 r2 'RoPE epilogue'"),
+    ("attn_d64", "flash-style attention, D = 64, non-causal, 64 seq × 16 heads × 1025", "ViT, 24 layers", "MFMA (VALU-issue limited)", 2500,
+     "6 vector instructions per score pair, 4 of the 8 issue slots are the two v_exp_f32: the softmax, not the MFMA, sets the pace at D = 64; + one extra block per (sequence, head) for query 0 (0.8 ms per step gross)", "§4 'Attention, round 3 / 4'"),
+    ("attn_d128_causal", "flash-style attention, D = 128, causal GQA, 8 seq × 16/8 heads × 2122 (+64 cached prefix keys)", "LLM, 24 layers (last: 5 queries per sequence)", "MFMA + VALU", 2500,
+     "one 32-query sub-block per wave (two would need ≈ 310 registers): MFMA and softmax of one unit serialise more than at D = 64; diagonal tiles run the masked general path", "§4 'Attention, round 3 / 4'"),
+    ("layernorm", "LayerNorm 1024, one wave per row", "ViT norm1 / norm2, 65 600 rows × 48", "HBM", 8000,
+     "4 B per element of traffic at 5.7-5.9 TB/s = the 6.3 TB/s this chip's HBM delivers to any kernel; only folding it into the GEMM removes it (built: model.norm_fusion, off for parity)", "§4 'Norm fusion, round 4'"),
+    ("rmsnorm", "RMSNorm 2048 (cast before gain), one wave per row", "LLM attention_norm / ffn_norm, 16 976 rows × 48", "HBM", 8000,
+     "as layernorm (5.0 TB/s: shorter launch, 35 MB per launch sits partly in the Infinity Cache)", "same"),
+    ("gemm256s_scale_res", "K-sliced 256² GEMM + finish kernel", "LLM w2 tail: 592 rows × 2048 × 8192 in 8 slices", "MFMA / fabric", 2500,
+     "a tail: 24 tiles cannot fill 256 CUs without slicing K, and the slices' fp32 images make a 50 MB round trip", "§4 'Tails, revisited'"),
+    ("gemm64_scale_res", "64×32 skinny GEMM", "ViT proj / fc2 tails: the 64 CLS rows of M = 65 600 = 256·256 + 64 (48 launches), last-layer rows", "latency", 2500,
+     "32 workgroups each walk K / 64 dependent LDS fills (≈ 20 µs at K = 4096): latency-bound by construction", "§4 r2 'skinny'"),
+    ("gemm128_bias", "128² GEMM (+ rope_split)", "LLM wqkv tail 592 × 4096 × 2048; heads", "L2→LDS fill", 2500,
+     "160 workgroups, one per CU, double-buffered only: ≈ 45 GB/s of LDS fill per CU; K-slicing at K = 2048 is a wash (measured r3)", "§4 'Tails, revisited'"),
+    ("gemm128_scale_res", "128² GEMM, residual epilogue", "LLM wo tail 592 × 2048 × 2048", "L2→LDS fill", 2500, "as gemm128_bias", "same"),
+    ("gemm64_bias_gelu", "64×32 skinny GEMM", "ViT fc1 tail (64 CLS rows)", "latency", 2500, "as gemm64_scale_res", "same"),
+    ("gemm64_bias", "64×32 skinny GEMM", "ViT qkv tail (64 CLS rows), gating layers", "latency", 2500, "as gemm64_scale_res", "same"),
+]
+F8 = [
+    ("gemm256f8_scale_res", "MXFP8 256² GEMM (v_mfma_scale_f32_16x16x128_f8f6f4), LayerScale / residual epilogue", "fc2, w2 main rows", 5000,
+     "the bf16 kernel's loop with twice the flops per LDS byte: 2 450 TFLOP/s is the same 0.85-0.95 of the held clock; bf16 residual stream in the epilogue"),
+    ("gemm256f8_silu_mul", "MXFP8 GEMM, SiLU·mul → MXFP8 output (block quantiser in pass B)", "w1∣w3", 5000, "as above; last round 75 % full"),
+    ("gemm256f8_bias_gelu", "MXFP8 GEMM, bias + GELU → MXFP8", "fc1", 5000,
+     "8 K-tiles per tile: the GELU table gathers + quantiser (≈ 10 µs) are as long as the main loop (profiles/r05_*_gemm_fp8_bench.txt: epilogue decomposition)"),
+    ("gemm256f8s_scale_res", "K-sliced MXFP8 GEMM + finish kernel (round 5)", "fc2 64-row tail (16 slices), w2 592-row tail (8 slices)", 5000,
+     "tails: before round 5 they were an extra, mostly empty round of full tiles (fc2: 5 rounds for 4.02 rounds of work)"),
+]
+
+
+def main():
+    line = load_line(sys.argv[1])
+    drv = load_line(sys.argv[2]) if len(sys.argv) > 2 else None
+    k = line["kernels"]
+    sec = line.get("secondary", {})
+    out = []
+    w = out.append
+    w("# KERNELS — state of the kernels on one page\n")
+    w(f"Headline workload (BASELINE.json configs[1]: 4 pairs = 8 videos × 8 frames @448², N = 2186 tokens per video, bf16, 1 MI355X): "
+      f"**{line['value']:.2f} pairs/s, {line['ms_per_step']:.2f} ms per step = {line['frac_of_mfma_roofline']:.3f} of the 96.9 pairs/s MFMA roofline** "
+      f"(`{os.path.relpath(sys.argv[1], ROOT)}`, a box of this round's pool; prefix cache "
+      f"{'on' if line['config'].get('prefix_cache') else 'off'}, last-layer query trimming {'on' if line['config'].get('trim_last_layer') else 'off'})."
+      + (f" The driver's own record: **{drv['value']:.2f} pairs/s** (`{os.path.basename(sys.argv[2])}`)." if drv else "") + "\n")
+    w("Every kernel is hand-written HIP for gfx950 (`mj-video_amd/csrc/`). Columns: time per 4-pair step from the profiled step of that "
+      "bench line (HIP events around every launch), achieved rate, fraction of the peak that bounds it (2.5 PFLOP/s dense bf16 MFMA, "
+      "8 TB/s HBM), the ONE reason it is not faster, and where DESIGN.md holds the measurements behind that sentence.\n")
+    w("| kernel (profiler tag) | what / where | ms per step | achieved | of peak | bound | the one reason it is not faster | DESIGN |")
+    w("|---|---|---|---|---|---|---|---|")
+    seen = 0.0
+    for tag, what, shapes, bound, peak, why, ref in ROWS:
+        r = k.get(tag)
+        if not r:
+            continue
+        seen += r["ms_per_step"]
+        if bound.startswith("HBM"):
+            ach, frac = f"{r['gbs']:.0f} GB/s", r["gbs"] / peak
+        else:
+            ach, frac = (f"{r['tflops']:.0f} TFLOP/s", r["tflops"] / peak) if r.get("tflops") else ("-", 0.0)
+        w(f"| `{tag}` | {what}; {shapes} | {r['ms_per_step']:.2f} | {ach} | {frac:.2f} | {bound} | {why} | {ref} |")
+    rest = sum(v["ms_per_step"] for v in k.values()) - seen
+    w(f"| (everything else) | patchify, CLS rows, embedding gather, pixel-shuffle LayerNorm, rope_split of tail rows, gating GEMMs, reward heads | "
+      f"{rest:.2f} | - | - | launch latency / HBM | small launches; < 1 % of the step | §4 table |\n")
+    f8 = sec.get("fp8_ffn") or {}
+    if f8.get("value"):
+        w(f"## fp8 FFN path (`model.set_ffn_format('mxfp8')`; `secondary.fp8_ffn` of the same line): {f8['value']:.2f} pairs/s, {f8['ms_per_step']:.2f} ms per step, "
+          f"{f8['mixed_roofline']['frac']:.3f} of its mixed roofline ({f8['mixed_roofline']['ceiling_pairs_per_s']} pairs/s: FFN flops at 5 PFLOP/s, the rest at 2.5)\n")
+        w("| kernel | what / where | ms per step | TFLOP/s | of 5 PFLOP/s | the one reason it is not faster |")
+        w("|---|---|---|---|---|---|")
+        for tag, what, shapes, peak, why in F8:
+            r = f8["fp8_kernels"].get(tag)
+            if r:
+                w(f"| `{tag}` | {what}; {shapes} | {r['ms_per_step']:.2f} | {r['tflops']:.0f} | {r['tflops'] / peak:.2f} | {why} |")
+        w("\nThe four attention-side Linears stay bf16: each of them on MXFP8 operands adds noise and none keeps 0 flips "
+          "(`profiles/r05_c_fp8_per_linear_study.txt`, DESIGN §4 'fp8, round 5').\n")
+    w("## The other configs of BASELINE.json, same process (`secondary`)\n")
+    w("| leg | config | pairs/s | ms per step | of its MFMA roofline |")
+    w("|---|---|---|---|---|")
+    for name, label in (("prefix_cache_off", "configs[1] with prefix cache and last-layer trimming OFF (every row, every forward)"),
+                        ("pairs8", "configs[2]'s shard: 8 pairs = 16 videos on one GPU (the weak-scaling baseline)"),
+                        ("c4_112_tiles", "configs[3]: 16 frames × 7 tiles = 112 tiles per video, N = 28 810")):
+        r = sec.get(name) or {}
+        if r.get("value"):
+            w(f"| `{name}` | {label} | {r['value']:.2f} | {r['ms_per_step']:.1f} | {r.get('frac_of_mfma_roofline', '-')} |")
+    w("\nNot on this page because they are not on the scoring path's clock: `preprocess.hip` (device-side `load_video` resize: 0.44 ms per "
+      "128 720p frames, DESIGN §6b), `mxfp8.hip` (weights quantised once).")
+    open(os.path.join(ROOT, "KERNELS.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
