@@ -24,9 +24,12 @@ def tag_of(k):
     m = re.match(r"t256::gemm256p_kernel<(\d)(?:, \d)?>", k)      # persistent form of the same tile kernel (round 3): same profiler tag
     if m:
         return "gemm256_" + EPI[int(m.group(1))]
-    m = re.match(r"gemm256f8_kernel<(\d), (true|false)>", k)      # MXFP8 operands (round 4)
+    m = re.match(r"gemm256f8_kernel<(\d), (true|false)(?:, (true|false))?>", k)      # MXFP8 operands (round 4; round 5: <EPI, OUT8, SPLIT>)
     if m:
-        return "gemm256f8_" + EPI[int(m.group(1))]
+        return "gemm256f8s_slices" if m.group(3) == "true" else "gemm256f8_" + EPI[int(m.group(1))]
+    m = re.match(r"splitk_finish256f8_kernel<(\d)", k)
+    if m:
+        return "gemm256f8s_finish_" + EPI[int(m.group(1))]
     if re.match(r"t256::gemm256_kernel<0, 7(?:, \d)?>", k):
         return "gemm256s_slices"        # K-sliced 256-tile launch: fp32 slice images to the workspace
     m = re.match(r"t256::splitk_finish256_kernel<(\d)>", k)
