@@ -170,6 +170,75 @@ def attn_case():
         fails.append(tag + f": {type(e).__name__}: {e}")
 
 
+def attn_ext_case():
+    """ABI 6 (round 5): causal launches with suffix queries (cu_seqlens_q) and / or a shared key / value prefix, against the ordinary
+    launch of the same kernel over the concatenated rows [prefix | own] - bit for bit (same key tiles, same arithmetic)"""
+    D = rng.choice([64, 128])
+    G = rng.choice([1, 2, 4])
+    KVH = rng.choice([1, 2])
+    H = KVH * G
+    P = rng.choice([0, 0, 64, 64, 128, 192])
+    nseq = rng.choice([1, 2, 3, 5])
+    pool = [1, 2, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 193, 256, 257, 321, 513, 577, 1025, rng.randrange(1, 1400), rng.randrange(1, 300)]
+    lens = [rng.choice(pool) for _ in range(nseq)]
+    if rng.random() < 0.1:
+        lens = [rng.choice([2122, 2186, 4097])]
+    style = rng.choice(["all", "tail5", "random", "one"])
+    qlens = [L if style == "all" else min(L, 5) if style == "tail5" else 1 if style == "one" else rng.randrange(1, L + 1) for L in lens]
+    if P == 0 and qlens == lens:
+        qlens[0] = max(1, lens[0] // 2)
+    mode = rng.choice([1, 2])
+    kern = rng.choice([0, 0, 7] + ([6] if D == 64 else []))
+    std = rng.choice([1.0, 2.5])
+    tag = f"attn_ext D={D} H={H} G={G} P={P} lens={lens} qlens={qlens} mode={mode} kernel={kern} std={std}"
+    try:
+        n_own = sum(lens)
+        pk = (torch.randn(max(P, 1), KVH * D, device=dev) * std).to(BF)[:P]
+        pv = torch.randn(max(P, 1), KVH * D, device=dev).to(BF)[:P]
+        qp = (torch.randn(max(P, 1), H * D, device=dev) * std).to(BF)[:P]
+        k_own = (torch.randn(n_own, KVH * D, device=dev) * std).to(BF)
+        v_own = torch.randn(n_own, KVH * D, device=dev).to(BF)
+        q_own = (torch.randn(n_own, H * D, device=dev) * std).to(BF)
+        ks, vs, qs, o = [], [], [], 0
+        for L in lens:
+            ks += [pk, k_own[o:o + L]]; vs += [pv, v_own[o:o + L]]; qs += [qp, q_own[o:o + L]]
+            o += L
+        kf, vf, qf = torch.cat(ks), torch.cat(vs), torch.cat(qs)
+        full_lens = [P + L for L in lens]
+        cum = lambda xs: torch.tensor([0] + list(torch.tensor(xs).cumsum(0)), dtype=torch.int32, device=dev)   # noqa: E731
+        cu_full, cu_k, cu_q = cum(full_lens), cum(lens), cum(qlens)
+        full = torch.empty(qf.shape[0], H * D, dtype=BF, device=dev)
+        ops.attention(qf, kf, vf, full, cu_full, max(full_lens), H, G, D, True, D ** -0.5, mode, kernel=kern)
+        ends = cu_full[1:].tolist()
+        want = torch.cat([full[e - lq:e] for e, lq in zip(ends, qlens)])
+        starts = cu_k[:-1].tolist()
+        q_sel = torch.cat([q_own[s0 + L - lq:s0 + L] for s0, L, lq in zip(starts, lens, qlens)])
+        got = torch.full((sum(qlens), H * D), float("nan"), dtype=BF, device=dev)
+        kw = {}
+        if qlens != lens:
+            kw.update(cu_seqlens_q=cu_q, max_seqlen_q=max(qlens))
+        if P:
+            kw.update(prefix_k=pk, prefix_v=pv)
+        ops.attention(q_sel, k_own, v_own, got, cu_k, max(lens), H, G, D, True, D ** -0.5, mode, kernel=kern, **kw)
+        torch.cuda.synchronize()
+        if not torch.isfinite(got.float()).all():
+            fails.append(tag + ": non-finite / unwritten cells")
+        elif not torch.equal(got, want):
+            fails.append(tag + f": {int((got != want).sum())} cells differ from the concatenated launch (max {float((got.float() - want.float()).abs().max()):.4f})")
+    except Exception as e:  # noqa: BLE001
+        fails.append(tag + f": {type(e).__name__}: {e}")
+
+
+_WS = None
+
+
+def _ws():
+    global _WS
+    if _WS is None:
+        _WS = torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return _WS
+
+
 def _fq(x):
     """MXFP8 fake-quantisation on the GPU (the arithmetic of oracle/ref_fp8.py in torch ops; the oracle itself is held to the
     kernels bit for bit by tests/test_fp8_gpu.py): block scale = smallest power of two with amax / s <= 448, elements e4m3 RNE"""
@@ -186,12 +255,18 @@ def gemm8_case():
     """MXFP8 operands (round 4): random M / N / K / epilogue, bf16 or MXFP8 output; exact on small-integer data"""
     M = rng.choice([1, 17, 64, 65, 200, 256, 257, 300, 513, 1025, 1104, rng.randrange(1, 2500), 256 * rng.randrange(1, 20) + rng.choice([0, 64, 80])])
     K = 128 * rng.choice([1, 2, 3, 4, 5, 8, 16, 17, 32, 64])
+    sliced = rng.random() < 0.5          # round 5: with a workspace, tails / under-filled launches run K-sliced (finish kernel's epilogues)
     epi = rng.choice(["bias", "nobias", "gelu", "relu", "scale_res", "silu"])
     out8 = epi in ("bias", "gelu", "relu", "silu") and rng.random() < 0.5
     N = (256 if out8 else 8) * rng.choice([1, 2, 3, 4, 8] if out8 else [1, 4, 16, 17, 32, 64, 96, 128, 129, 256, rng.randrange(1, 200)])
     if epi == "silu" and N % 32:
         N = (N + 31) // 32 * 32
-    if M * N > 20_000_000 or M * K > 20_000_000 or N * K > 20_000_000:
+    if sliced and rng.random() < 0.3:    # shapes that really peel a tail: a few tiles beyond whole rounds of 256
+        M, N = 256 * rng.choice([8, 9]) + rng.choice([64, 80, 200]), 256 * rng.choice([28, 31, 32])
+        if epi == "silu":
+            N = 256 * 32
+        K = 128 * rng.choice([8, 16])
+    if M * N > 21_000_000 or M * K > 20_000_000 or N * K > 20_000_000:
         return
     integer = rng.random() < 0.4 and epi in ("bias", "nobias", "relu") and not out8
     if integer:
@@ -202,7 +277,8 @@ def gemm8_case():
         a = torch.randn(M, K, device=dev).to(BF)
         w = (torch.randn(N, K, device=dev) * 0.08).to(BF)
         b = (torch.randn(N, device=dev) * 0.2).to(BF)
-    tag = f"gemm8 M={M} N={N} K={K} epi={epi} out8={out8} int={integer}"
+    tag = f"gemm8 M={M} N={N} K={K} epi={epi} out8={out8} int={integer} ws={sliced}"
+    wsk = dict(workspace=_ws()) if sliced else {}
     try:
         a8, w8 = ops.quantize_mxfp8(a), ops.quantize_mxfp8(w)
         aq, wq = _fq(a).double(), _fq(w).double()
@@ -220,10 +296,10 @@ def gemm8_case():
             w13 = torch.stack([w[:nout].view(nout // 16, 16, K), w[nout:].view(nout // 16, 16, K)], dim=1).reshape(N, K).contiguous()
             wk = ops.quantize_mxfp8(w13)
         o16 = torch.empty(M, nout, dtype=BF, device=dev)
-        ops.gemm(a8, wk, o16, code, bias=bias, **kw)
+        ops.gemm(a8, wk, o16, code, bias=bias, **kw, **wsk)
         if out8:
             o8 = ops.MX8.empty(M, nout, dev)
-            ops.gemm(a8, wk, o8, code, bias=bias)
+            ops.gemm(a8, wk, o8, code, bias=bias, **wsk)
             chk = ops.quantize_mxfp8(o16)
             torch.cuda.synchronize()
             if not torch.equal(o8.data, chk.data):
@@ -314,20 +390,22 @@ def folded_case():
 
 
 t0 = time.time()
-n_g = n_a = n_8 = n_f = 0
+n_g = n_a = n_8 = n_f = n_x = 0
 while time.time() - t0 < budget:
     x_ = rng.random()
-    if x_ < 0.35:
+    if x_ < 0.30:
         gemm_case(); n_g += 1
-    elif x_ < 0.65:
+    elif x_ < 0.55:
         attn_case(); n_a += 1
+    elif x_ < 0.67:
+        attn_ext_case(); n_x += 1
     elif x_ < 0.85:
         gemm8_case(); n_8 += 1
     else:
         folded_case(); n_f += 1
     if len(fails) > 30:
         break
-print(f"{n_g} GEMM cases, {n_a} attention cases, {n_8} MXFP8 GEMM cases, {n_f} folded-norm cases in {time.time() - t0:.0f} s (seed {seed}): {len(fails)} failures")
+print(f"{n_g} GEMM cases, {n_a} attention cases, {n_x} suffix-query / shared-prefix attention cases, {n_8} MXFP8 GEMM cases, {n_f} folded-norm cases in {time.time() - t0:.0f} s (seed {seed}): {len(fails)} failures")
 for f in fails:
     print("FAIL", f)
 sys.exit(1 if fails else 0)
