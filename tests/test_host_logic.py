@@ -371,6 +371,33 @@ def test_analyse_ids_prefix_skip_and_tail():
     assert model._analyse_ids(lids.numpy(), lmask.numpy().astype(bool), 6, lambda p: True)["skip"] == 128
 
 
+def test_prefix_candidate_on_prompts_built_by_prepare_chat_input():
+    """the prompts the eval harness builds (``video_prefix`` + caption through ``prepare_chat_input``, eval_genai_mjvideo.py:132-139) share
+    everything up to the first <IMG_CONTEXT>: BOS, the system turn, ``<|im_start|>user\nFrame1: <img>`` - the prefix the cache
+    keys on - whatever the captions are; with the stub tokenizer (one id per character) that is 98 tokens, so 64 are cacheable"""
+    cfg = make_cfg("tiny", 56)
+    model = InternVLChatRewardModeling.from_config(cfg)
+    model.config.pad_token_id = 2
+    model.model.img_context_token_id = StubTokenizer.special["<IMG_CONTEXT>"]
+    tok, rows = StubTokenizer(), []
+    for caption in ("a cat sits on a mat", "two dogs run along the beach at dusk, wide shot"):
+        ids, _ = chat_input.prepare_chat_input(cfg, tok, torch.zeros(2, 3, 56, 56), chat_input.video_prefix(2) + caption, {})
+        rows.append(ids)
+    n = max(int(r.shape[1]) for r in rows)
+    ids = torch.full((2, n), 2, dtype=torch.long)
+    mask = torch.zeros(2, n, dtype=torch.bool)
+    for i, r in enumerate(rows):
+        ids[i, : r.shape[1]] = r[0]
+        mask[i, : r.shape[1]] = True
+    first_ctx = [int(np.flatnonzero(ids[i].numpy() == model.model.img_context_token_id)[0]) for i in range(2)]
+    assert first_ctx[0] == first_ctx[1] and (ids[0, : first_ctx[0]] == ids[1, : first_ctx[0]]).all()
+    per_tile = chat_input.num_image_tokens_per_tile(cfg)
+    seen = []
+    info = model._analyse_ids(ids.numpy(), mask.numpy(), 4, lambda p: seen.append(len(p)) or True)   # 2 videos x 2 tiles
+    assert seen == [(first_ctx[0] // 64) * 64] and info["skip"] == seen[0] > 0
+    assert info["img_rows"].size == 2 * 2 * per_tile and (info["ids"][info["img_rows"]] == model.model.img_context_token_id).all()
+
+
 def test_custom_output_access():
     o = CustomOutput(rewards=torch.ones(1), score=torch.zeros(1))
     assert o["score"] is o.score and o[0] is o.rewards and o.keys() == ["rewards", "score"]
