@@ -386,6 +386,8 @@ class InternVLChatRewardModeling(nn.Module):
         #   as the reference does.
         self.prefix_cache = True
         self._prefix = None          # dict(key, P, k [layers][P, kv*128], v [layers][P, ld of the layer's V rows], v_last)
+        self._prefix_misses = 0      # consecutive forwards that found no cached prefix (see _forward_group: thrash guard)
+        self._prefix_last_miss = None
         self.prefix_cache_hits = 0   # forwards served from the cache (tests / bench report)
 
     # -- construction helpers -------------------------------------------------------------------
@@ -1039,11 +1041,22 @@ class InternVLChatRewardModeling(nn.Module):
             c = self._prefix
             hit.append(c is not None and c["settings"] == settings and c["ids"].shape == prefix_ids.shape
                        and bool((c["ids"] == prefix_ids).all()))
-            if not hit[0]:
-                # a prefix this model holds no keys / values for (first forward, new weights, another prompt, another setting):
-                # computed once, by a pass over the prefix tokens ALONE, before this forward's tower - so that a forward's result
-                # never depends on whether the cache was warm (the same cached computation either way)
-                self._build_prefix(d, prefix_ids, settings, int(input_ids.shape[1]), dev)
+            if hit[0]:
+                self._prefix_misses = 0
+                return True
+            # a prefix this model holds no keys / values for (first forward, new weights, another prompt, another setting):
+            # computed once, by a pass over the prefix tokens ALONE, before this forward's tower - so that a forward's result
+            # never depends on whether the cache was warm (the same cached computation either way).  A caller whose prompts
+            # share NO constant prefix (every forward another one) would pay that pass - about 3 ms - for nothing each time:
+            # after three misses in a row the prefix is only rebuilt when a candidate REPEATS, and forwards in between run
+            # uncached (every row, as prefix_cache = False does).
+            key = (settings, prefix_ids.tobytes())
+            self._prefix_misses += 1
+            repeat = self._prefix_last_miss == key
+            self._prefix_last_miss = key
+            if self._prefix_misses > 3 and not repeat:
+                return False
+            self._build_prefix(d, prefix_ids, settings, int(input_ids.shape[1]), dev)
             return True
 
         info = self._analyse_ids(input_ids, attention_mask, pixel_values.shape[0], lookup if use_prefix else None)  # host arrays

@@ -580,6 +580,7 @@ def test_prefix_cache_is_invisible_and_invalidates(cuda, fmt):
         model.prefix_cache = True
         model.attention_scores = "flash"
         # invalidation 2: another prefix (one system token changed in every sample)
+        model._prefix_misses = 0          # (the thrash guard, tested below, counts consecutive misses)
         model.forward(px, ids, mask)
         hits = model.prefix_cache_hits
         ids3 = ids.clone()
@@ -591,6 +592,7 @@ def test_prefix_cache_is_invisible_and_invalidates(cuda, fmt):
         assert fields_equal(changed, model.forward(px, ids3, mask)) == []
         model.prefix_cache = True
         # invalidation 3: new weights
+        model._prefix_misses = 0
         model.forward(px, ids, mask)
         hits = model.prefix_cache_hits
         sd2 = synth.synth_state_dict(cfg, seed=1, lm_head=False)
@@ -600,6 +602,29 @@ def test_prefix_cache_is_invisible_and_invalidates(cuda, fmt):
         assert model.prefix_cache_hits == hits and fields_equal(new_w, ref) != []
         hit = model.forward(px, ids, mask)
         assert model.prefix_cache_hits == hits + 1 and fields_equal(hit, new_w) == []
+        # thrash guard: prompts that share no constant prefix (another one every forward) stop paying the prefix pass after three
+        # misses in a row - those forwards run uncached - until a prefix repeats
+        model._prefix, model._prefix_misses, model._prefix_last_miss = None, 0, None
+        hits = model.prefix_cache_hits
+        built = []
+        for step in range(6):
+            ids_v = ids.clone()
+            ids_v[:, 5] += 1 + step
+            before = model._prefix
+            out_v = model.forward(px, ids_v, mask)
+            built.append(model._prefix is not before)
+            if step == 5:
+                model.prefix_cache = False
+                assert fields_equal(out_v, model.forward(px, ids_v, mask)) == []
+                model.prefix_cache = True
+        assert built == [True, True, True, False, False, False] and model.prefix_cache_hits == hits
+        ids_v = ids.clone()
+        ids_v[:, 5] += 6
+        before = model._prefix
+        model.forward(px, ids_v, mask)                      # the candidate of step 5 again: rebuilt ...
+        assert model._prefix is not before and model.prefix_cache_hits == hits
+        model.forward(px, ids_v, mask)                      # ... and served
+        assert model.prefix_cache_hits == hits + 1 and model._prefix_misses == 0
     finally:
         model.use_gemm_workspace = True
     # with K-slicing on: re-association noise only (bound as in test_last_layer_trimming_is_invisible)
