@@ -378,12 +378,12 @@ class InternVLChatRewardModeling(nn.Module):
         self.trim_last_layer = True
         # prefix_cache: every prompt starts with the same tokens (system prompt + "Frame1: <img>": conversation.py:354-365,
         #   eval_genai_mjvideo.py:132-137); under the causal mask their hidden states - and so their keys / values in all 24
-        #   layers - depend on the weights and those ids alone.  The first forward that meets a prefix computes it like any other
-        #   rows and keeps the K / V rows of its first 64 * k tokens (per layer; the copy of sample 0's rows); later forwards with
-        #   the same prefix, weights and settings leave those rows out of every GEMM / norm of the tower and attend to the
-        #   cached keys (mjv_attn_desc.prefix_k / prefix_v).  Invalidated by any parameter change (load_state_dict, .to()),
-        #   another prefix, another rotary base (dynamic NTK), another numerics setting.  False = recompute them every forward,
-        #   as the reference does.
+        #   layers - depend on the weights and those ids alone.  The first forward that meets a prefix runs the tower over its
+        #   first 64 * k tokens ALONE (_build_prefix) and keeps every layer's K / V rows; every forward - that first one included,
+        #   so a result never depends on whether the cache was warm - leaves those rows out of every GEMM / norm of the tower
+        #   and attends to the cached keys (mjv_attn_desc.prefix_k / prefix_v).  Invalidated by any parameter change
+        #   (load_state_dict, .to()), another prefix, another rotary base (dynamic NTK), another numerics setting.  False =
+        #   recompute them every forward, as the reference does.
         self.prefix_cache = True
         self._prefix = None          # dict(key, P, k [layers][P, kv*128], v [layers][P, ld of the layer's V rows], v_last)
         self._prefix_misses = 0      # consecutive forwards that found no cached prefix (see _forward_group: thrash guard)
@@ -1064,8 +1064,11 @@ class InternVLChatRewardModeling(nn.Module):
         prefix = self._prefix if info["skip"] else None
         if prefix is not None and hit[0]:
             self.prefix_cache_hits += 1
-            if prefix["stream"] != torch.cuda.current_stream(dev).cuda_stream:
-                torch.cuda.current_stream(dev).wait_event(prefix["ready"])
+            cur = torch.cuda.current_stream(dev)
+            if prefix["stream"] != cur.cuda_stream:   # built on another stream: wait for the rows, and tell the allocator who reads them
+                cur.wait_event(prefix["ready"])
+                for t in prefix["k"] + prefix["v"] + [prefix["v_last"]]:
+                    t.record_stream(cur)
 
         def up(a):
             return torch.from_numpy(a).to(dev, non_blocking=True)
