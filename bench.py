@@ -445,6 +445,11 @@ def main():
                        # constant prompt prefix (first 64 k tokens: system prompt + "Frame1: <img>") come from a cache filled by
                        # the first forward, and the last decoder layer computes queries only from the first selected row on.
                        # secondary.prefix_cache_off is the same workload with both off (every row, every forward)
+                       "prefix_cache_note": ("steady-state work removal, stated: the keys / values of the prompt's constant first 64 k tokens "
+                                             "(system turn + 'Frame1: <img>') come from a per-model cache filled once by a pass over those "
+                                             "tokens alone, and the last decoder layer computes queries only from the first row the heads "
+                                             "read; outputs equal the full computation up to fp32 re-association (bit for bit when no GEMM "
+                                             "slices K); secondary.prefix_cache_off = both switches off, every row in every forward"),
                        "prefix_cache": bool(model.prefix_cache), "prefix_cache_tokens": (model._prefix or {}).get("P", 0),
                        "prefix_cache_hits": model.prefix_cache_hits, "trim_last_layer": bool(model.trim_last_layer),
                        "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
