@@ -92,6 +92,35 @@ constexpr int SCALE_OFF = EPI_TILE_BYTES + GELU_BYTES;   // ring of 4 K-tiles' s
 constexpr int SCALE_SLOT = 2048;
 constexpr int LDS_BYTES = SCALE_OFF + 4 * SCALE_SLOT;
 static_assert(EPI_TILE_BYTES >= PIPE_BYTES && LDS_BYTES <= 160 * 1024 && SCALE_OFF % 16 == 0, "LDS budget");
+// GELU epilogue (round 5: gemm.hip's round-4 form): the table's two sign halves sit 64 KiB apart in LDS - x > 0 at byte 0, x < 0
+// at byte 65536 - so that the gather address is the rounded value's own bit pattern, (fp32 bits >> 15) - 2 LO = 65536 sign +
+// 2 (magnitude - LO), and the range test is one wave-wide vote on running min / max: 5.5 vector instructions per element where the
+// contiguous table took 9.  This kernel's pipeline owns bytes 0 .. 128 Ki during the main loop, so the table waits behind it
+// (where the prologue's DMA put it) and is moved to its two windows at the head of the epilogue (960 16-byte chunks, one barrier);
+// the staged output tile is split around the second window: rows 0 .. 108 between the windows, rows 109 .. 255 above.
+constexpr int G8_NEG = 65536;
+constexpr int G8_HALF = MJV_GELU_NEG_OFF * 2;                 // 7 680 bytes per sign half
+constexpr int G8_A0 = G8_HALF, G8_AROWS = (G8_NEG - G8_A0) / EPI_PITCH;
+constexpr int G8_B0 = G8_NEG + G8_HALF;
+static_assert(MJV_GELU_TABLE_LEN == 2 * MJV_GELU_NEG_OFF && MJV_GELU_R <= MJV_GELU_NEG_OFF && G8_HALF % 16 == 0, "table halves");
+static_assert(G8_A0 + G8_AROWS * EPI_PITCH <= G8_NEG && G8_B0 + (256 - G8_AROWS) * EPI_PITCH <= LDS_BYTES && G8_B0 % 16 == 0, "GELU LDS map");
+template <bool GL>
+MJV_DEV int erow8(int ml) {   // LDS byte offset of row ml of the staged output tile
+  return GL ? ml * EPI_PITCH + (ml < G8_AROWS ? G8_A0 : G8_B0 - G8_AROWS * EPI_PITCH) : ml * EPI_PITCH;
+}
+// general form of the table GELU on the split table (gelu_lut's logic; lds = LDS base)
+MJV_DEV float gelu_lut_split8(float xf, const char* lds) {
+  const unsigned u = __float_as_uint(xf);
+  const unsigned mag = (u >> 16) & 0x7fffu;
+  const unsigned rel = mag - MJV_GELU_LO;
+  const unsigned sgn = (unsigned)((int)u >> 31);
+  const bool in_tab = rel < (unsigned)MJV_GELU_R;
+  const unsigned t = *(const u16*)(lds + (sgn & G8_NEG) + (in_tab ? rel * 2 : 0u));
+  const unsigned big = gelu_beyond_table(u, mag);
+  const unsigned small = __float_as_uint(0.5f * xf);
+  const unsigned other = mag < MJV_GELU_LO ? small : big;
+  return __uint_as_float(in_tab ? (t << 16) : other);
+}
 
 struct StagePtrs {
   const uint8_t* src[4][2];
@@ -337,7 +366,18 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
 
   // ---- epilogue: pass A (fragments -> bf16 tile in LDS, bias / activation), pass B (rows -> global), as gemm256_kernel
   char* etile = smem;
-  u16* gtab = (u16*)(smem + EPI_TILE_BYTES);
+  constexpr bool GL = EPI == MJV_EPI_BIAS_GELU;
+  if constexpr (GL) {
+    // the table from behind the pipeline (contiguous: [x > 0 | x < 0]) to its two windows; every wave is past its last fragment read
+    static_assert(MJV_GELU_TABLE_LEN / 8 <= 1024 && G8_HALF / 16 == 480, "two chunks per thread cover the table");
+    const u32x4* src = (const u32x4*)(smem + EPI_TILE_BYTES);
+    u32x4 c0, c1 = {0u, 0u, 0u, 0u};
+    c0 = src[tid];
+    if (tid + 512 < MJV_GELU_TABLE_LEN / 8) c1 = src[tid + 512];
+    *(u32x4*)(smem + (tid < 480 ? tid * 16 : G8_NEG + (tid - 480) * 16)) = c0;
+    if (tid + 512 < MJV_GELU_TABLE_LEN / 8) *(u32x4*)(smem + G8_NEG + (tid + 512 - 480) * 16) = c1;
+    __syncthreads();
+  }
   constexpr int OUT_COLS = (EPI == MJV_EPI_SILU_MUL) ? 128 : 256;
   constexpr int LANES_PER_ROW = OUT_COLS / 8;
   constexpr int ROWS_PER_PASS = 512 / LANES_PER_ROW;
@@ -367,28 +407,31 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
                          __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
     if (EPI == MJV_EPI_SILU_MUL && (j & 1)) continue;
     if constexpr (EPI == MJV_EPI_BIAS_GELU) {
-      unsigned ubs[8][4], idx[8][4];
-      bool all_in = true;
+      // a whole column group (8 fragments = 32 elements per lane) at a time: ONE wave-wide range test on the running min / max of
+      // |x| (IEEE-2019 maximum / minimum: a NaN makes the vote fail), then 32 gathers in flight together (gemm.hip pass A)
+      unsigned ubs[8][4];
+      float amax = 0.f, amin = __uint_as_float(0x7f000000u);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          ubs[i][r] = __float_as_uint(rbf(acc[i][j][r] + b4[r]));
-          const unsigned rel = ((ubs[i][r] >> 16) & 0x7fffu) - MJV_GELU_LO;
-          all_in = all_in && (rel < (unsigned)MJV_GELU_R);
-          idx[i][r] = rel + (ubs[i][r] >> 31) * (unsigned)MJV_GELU_NEG_OFF;
+          const float xr = rbf(acc[i][j][r] + b4[r]);
+          ubs[i][r] = __float_as_uint(xr);
+          amax = __builtin_elementwise_maximum(amax, fabsf(xr));
+          amin = __builtin_elementwise_minimum(amin, fabsf(xr));
         }
+      const bool all_in = amin >= __uint_as_float((unsigned)MJV_GELU_LO << 16) && amax < __uint_as_float((unsigned)MJV_GELU_HI << 16);
       if (__all(all_in)) {
         unsigned t[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) t[i][r] = gtab[idx[i][r]];
+          for (int r = 0; r < 4; ++r) t[i][r] = *(const u16*)(smem + ((ubs[i][r] >> 15) - 2u * MJV_GELU_LO));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int ml = wr * 128 + i * 16 + l15;
           const u32x2 o = {t[i][0] | (t[i][1] << 16), t[i][2] | (t[i][3] << 16)};
-          *(u32x2*)(etile + ml * EPI_PITCH + nl * 2) = o;
+          *(u32x2*)(etile + erow8<GL>(ml) + nl * 2) = o;
         }
       } else {
 #pragma unroll
@@ -396,9 +439,9 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
           const int ml = wr * 128 + i * 16 + l15;
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_lut(__uint_as_float(ubs[i][r]), gtab);
+          for (int r = 0; r < 4; ++r) v[r] = gelu_lut_split8(__uint_as_float(ubs[i][r]), smem);
           const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-          *(u32x2*)(etile + ml * EPI_PITCH + nl * 2) = o;
+          *(u32x2*)(etile + erow8<GL>(ml) + nl * 2) = o;
         }
       }
       continue;
@@ -428,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(Gemm8Args p) {
   __syncthreads();
   u32x4 vals[PASSES];
 #pragma unroll
-  for (int it = 0; it < PASSES; ++it) vals[it] = *(const u32x4*)(etile + (it * ROWS_PER_PASS + ml0) * EPI_PITCH + c8 * 2);
+  for (int it = 0; it < PASSES; ++it) vals[it] = *(const u32x4*)(etile + erow8<GL>(it * ROWS_PER_PASS + ml0) + c8 * 2);
   if constexpr (OUT8) {
     // the row's 32-column blocks are the quads of lanes: block-quantise the bf16 values on the way out (every lane takes part
     // in the quad exchange, rows / columns beyond the problem are simply not stored; nlim % 128 == 0 keeps quads whole)

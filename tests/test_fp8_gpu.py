@@ -137,6 +137,40 @@ def test_gemm_mxfp8_exact_integers(cuda, M, N, K):
     assert torch.equal(out.cpu(), ref), f"{(out.cpu() != ref).sum().item()} of {ref.numel()} differ"
 
 
+@pytest.mark.parametrize("out8", [False, True])
+def test_gemm_mxfp8_gelu_epilogue_every_bf16_value(cuda, out8):
+    """the fp8 kernel's GELU epilogue (round 5: the split-table form of the bf16 kernel - gather address = the value's bit pattern,
+    one wave-wide range vote) on EVERY bf16 value, NaNs and infinities included: A = 0, so a pre-activation is its column's bias
+    exactly; 256 values per launch = 16 votes of 16 columns, natural order (whole votes inside / outside the table) and
+    shuffled (mixed votes -> the general path).  Bit for bit torch's CPU bf16 GELU (NaN where it gives NaN); the MXFP8 output
+    equals the quantised bf16 output."""
+    from mj_video_amd import ops
+    M, N, K = 256, 256, 128
+    a8 = ops.quantize_mxfp8(torch.zeros(M, K, dtype=BF, device=cuda))
+    w8 = ops.quantize_mxfp8(rnd(N, K, seed=2).to(cuda))
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(BF)
+    for order in ("natural", "shuffled"):
+        v = bits if order == "natural" else bits[torch.randperm(65536, generator=torch.Generator().manual_seed(11))]
+        for c0 in range(0, 65536, N):
+            b = v[c0:c0 + N]
+            out = torch.empty(M, N, dtype=BF, device=cuda)
+            ops.gemm(a8, w8, out, ops.EPI_BIAS_GELU, bias=b.to(cuda))
+            ref = F.gelu(b)
+            got = out[[0, 77, 255]].cpu()
+            want = ref.expand(3, N)
+            nan = torch.isnan(want)
+            assert torch.equal(torch.isnan(got), nan), (order, c0)
+            same = got.view(torch.int16) == want.view(torch.int16)
+            same |= (got.float() == 0) & (want.float() == 0)
+            same |= b.float().abs().expand(3, N) < 2.0 ** -125       # (torch flushes subnormal results, the table's x / 2 keeps them)
+            assert (same | nan).all(), (order, c0, b[~(same | nan)[0]][:8], got[0][~(same | nan)[0]][:8], ref[~(same | nan)[0]][:8])
+            if out8 and not nan.any() and torch.isfinite(ref.float()).all():
+                o8 = ops.MX8.empty(M, N, cuda)
+                ops.gemm(a8, w8, o8, ops.EPI_BIAS_GELU, bias=b.to(cuda))
+                chk = ops.quantize_mxfp8(out)
+                assert torch.equal(o8.data, chk.data) and torch.equal(o8.scales, chk.scales), (order, c0)
+
+
 @pytest.mark.parametrize("M,N,K", [(2112, 8192, 1024),    # 9 x 32 tiles on 256 CUs: a 64-row tail peeled off and sliced 4 x
                                    (2304 + 80, 7168, 2048),  # 10 x 28 = 280 tiles: the last m-tile (80 rows) peeled, sliced 8 x
                                    (200, 512, 4096),         # under-filled as a whole (2 tiles): sliced 16 x

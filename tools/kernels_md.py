@@ -54,7 +54,7 @@ F8 = [
      "the bf16 kernel's loop with twice the flops per LDS byte: 2 450 TFLOP/s is the same 0.85-0.95 of the held clock; bf16 residual stream in the epilogue"),
     ("gemm256f8_silu_mul", "MXFP8 GEMM, SiLU·mul → MXFP8 output (block quantiser in pass B)", "w1∣w3", 5000, "as above; last round 75 % full"),
     ("gemm256f8_bias_gelu", "MXFP8 GEMM, bias + GELU → MXFP8", "fc1", 5000,
-     "8 K-tiles per tile: a 13 µs main loop against 3.5 µs of fixed costs + 5.4 µs of GELU table gathers (LDS-bound) + 0.8 µs of block quantiser (profiles/r05_i_gemm_fp8_bench.txt: epilogue decomposition)"),
+     "8 K-tiles per tile: a 13 µs main loop against 3 µs of fixed costs + 4.2 µs of GELU table gathers (LDS-bound) + 0.5-1.5 µs of block quantiser (profiles/r05_v_gemm_fp8_bench.txt: epilogue decomposition)"),
     ("gemm256f8s_scale_res", "K-sliced MXFP8 GEMM + finish kernel (round 5)", "fc2 64-row tail (16 slices), w2 592-row tail (10 slices)", 5000,
      "tails: before round 5 they were an extra, mostly empty round of full tiles (fc2: 5 rounds for 4.02 rounds of work)"),
 ]
