@@ -19,6 +19,11 @@
 // Epilogues: the bf16 ones (same code, same rounding points), and - c_format MXFP8 - the bf16 result block-quantised in pass B
 // (a row's 32 columns are 4 neighbouring lanes there), so the GELU / SiLU*up outputs go to the next fp8 GEMM without a
 // separate quantise pass and at half the store bytes.
+//
+// Round 5: (i) the m-tile rows of an under-filled last round, and launches that under-fill the chip as a whole, run K-SLICED
+// (gemm256f8_kernel<.., SPLIT> writes fp32 accumulator images, splitk_finish256f8_kernel sums them in slice order and runs
+// every epilogue incl. the block quantiser) - mjv_gemm_mxfp8_dispatch plans it like gemm.hip plans the bf16 tails; (ii) the
+// GELU epilogue takes the split-table form of gemm.hip's round-4 pass A (G8_* below).
 #include "mx8.h"
 #include "gelu_table.h"
 #include <atomic>
