@@ -163,7 +163,7 @@ def time_forwards(model, px, ids, mask, pairs, steps, warmup, profile=False):
             "steps": steps, "warmup": warmup, "pairs_per_step": pairs}, res
 
 
-def secondary_legs(model, cfg, dev, px, ids, mask, seq_len):
+def secondary_legs(model, cfg, dev, px, ids, mask):
     """The configs the default command line is not quoted on (module docstring "secondary"), each in its own try block."""
     sec = {}
 
@@ -518,7 +518,7 @@ def main():
                                "note": "back-to-back single-video forwards, not part of `value`"}
         if (world == 1 and not use_dist and not args.no_secondary and not args.fp8 and (S, F, args.pairs) == (448, 8, 4)
                 and not os.environ.get("MJV_BENCH_NORM_FUSION") and not args.gemm_code):
-            line["secondary"] = secondary_legs(model, cfg, dev, px, ids, mask, seq_len)
+            line["secondary"] = secondary_legs(model, cfg, dev, px, ids, mask)
         if world == 1 and not args.no_cpu_baseline and not args.fp8:
             # oneDNN bf16 GEMMs stop scaling (and oversubscribe NUMA domains) far below a 256-thread host: cap at 32
             cpu_model, phys, logical = host_cpu_info()
