@@ -60,8 +60,28 @@ F8 = [
 ]
 
 
+def mfma_busy():
+    """tag -> MFMA-pipe busy share from the committed PMC summary (tools/mfma_busy_summary.py), if there is one"""
+    import glob
+    import re
+    out = {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_pipe_busy.txt")))
+    if not files:
+        return out
+    epi = ["bias", "bias_gelu", "bias_relu", "scale_res", "silu_mul", "rope_qkv"]
+    for ln in open(files[-1]):
+        m = re.match(r"t256::gemm256p?_kernel<(\d), 0.*\s(\d\.\d+)\s*$", ln)
+        if m:
+            out["gemm256_" + epi[int(m.group(1))]] = float(m.group(2))
+        m = re.match(r"v2::attn2_kernel<(\d+), (true|false).*\s(\d\.\d+)\s*$", ln)
+        if m:
+            out["attn_d" + m.group(1) + ("_causal" if m.group(2) == "true" else "")] = float(m.group(3))
+    return out
+
+
 def main():
     line = load_line(sys.argv[1])
+    busy = mfma_busy()
     drv = load_line(sys.argv[2]) if len(sys.argv) > 2 else None
     k = line["kernels"]
     sec = line.get("secondary", {})
@@ -75,9 +95,10 @@ def main():
       + (f" The driver's own record: **{drv['value']:.2f} pairs/s** (`{os.path.basename(sys.argv[2])}`)." if drv else "") + "\n")
     w("Every kernel is hand-written HIP for gfx950 (`mj-video_amd/csrc/`). Columns: time per 4-pair step from the profiled step of that "
       "bench line (HIP events around every launch), achieved rate, fraction of the peak that bounds it (2.5 PFLOP/s dense bf16 MFMA, "
-      "8 TB/s HBM), the ONE reason it is not faster, and where DESIGN.md holds the measurements behind that sentence.\n")
-    w("| kernel (profiler tag) | what / where | ms per step | achieved | of peak | bound | the one reason it is not faster | DESIGN |")
-    w("|---|---|---|---|---|---|---|---|")
+      "8 TB/s HBM), the MFMA pipe's busy share by the PMC counters (of the cycles the chip actually ran: it holds 1.7-2.0 GHz of its 2.4 "
+      "under these kernels), the ONE reason it is not faster, and where DESIGN.md holds the measurements behind that sentence.\n")
+    w("| kernel (profiler tag) | what / where | ms per step | achieved | of peak | MFMA busy | bound | the one reason it is not faster | DESIGN |")
+    w("|---|---|---|---|---|---|---|---|---|")
     seen = 0.0
     for tag, what, shapes, bound, peak, why, ref in ROWS:
         r = k.get(tag)
@@ -88,10 +109,10 @@ def main():
             ach, frac = f"{r['gbs']:.0f} GB/s", r["gbs"] / peak
         else:
             ach, frac = (f"{r['tflops']:.0f} TFLOP/s", r["tflops"] / peak) if r.get("tflops") else ("-", 0.0)
-        w(f"| `{tag}` | {what}; {shapes} | {r['ms_per_step']:.2f} | {ach} | {frac:.2f} | {bound} | {why} | {ref} |")
+        w(f"| `{tag}` | {what}; {shapes} | {r['ms_per_step']:.2f} | {ach} | {frac:.2f} | {busy.get(tag, '-')} | {bound} | {why} | {ref} |")
     rest = sum(v["ms_per_step"] for v in k.values()) - seen
     w(f"| (everything else) | patchify, CLS rows, embedding gather, pixel-shuffle LayerNorm, rope_split of tail rows, gating GEMMs, reward heads | "
-      f"{rest:.2f} | - | - | launch latency / HBM | small launches; < 1 % of the step | §4 table |\n")
+      f"{rest:.2f} | - | - | - | launch latency / HBM | small launches; < 1 % of the step | §4 table |\n")
     f8 = sec.get("fp8_ffn") or {}
     if f8.get("value"):
         w(f"## fp8 FFN path (`model.set_ffn_format('mxfp8')`; `secondary.fp8_ffn` of the same line): {f8['value']:.2f} pairs/s, {f8['ms_per_step']:.2f} ms per step, "
