@@ -30,6 +30,8 @@
  * ABI 6 adds, at the END of the attention descriptor (all zero = ABI 5): suffix queries (cu_seqlens_q) and a shared key / value
  * prefix (prefix_k / prefix_v) for causal launches - the two pieces of work a scorer can leave out of the language tower - and
  * lets MJV_EPI_ROPE_QKV run with rope_group 0 (a k | v projection without q heads).
+ * ABI 7 adds what the Phi-3-mini language tower of BASELINE configs[4] needs beyond the InternLM2 one: head_dim 96 in
+ * mjv_attention_bf16 and mjv_rope_heads_bf16 (rotary embedding in place on a [q | k | v] projection).
  */
 #ifndef MJV_H_
 #define MJV_H_
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MJV_ABI_VERSION 6
+#define MJV_ABI_VERSION 7
 
 enum {
   MJV_OK = 0,
@@ -179,7 +181,7 @@ typedef struct mjv_attn_desc {
   const int32_t* cu_seqlens;  /* [n_seqs + 1] packed row offsets (device) */
   int32_t n_seqs, max_seqlen;
   int32_t n_heads, kv_group;
-  int32_t head_dim;           /* 64 or 128 */
+  int32_t head_dim;           /* 64, 128, or (ABI 7; kernel 0 / 7 only) 96 - Phi-3-mini's heads: dense 192-byte K / V rows in LDS */
   int32_t causal;
   float scale;
   int32_t score_round_mode;
@@ -243,6 +245,16 @@ int mjv_row_stats_bf16(const mjv_bf16* x, int64_t ldx, float* rstd, float* mean_
 int mjv_rope_split_bf16(const mjv_bf16* qkv, int64_t ldqkv, mjv_bf16* q, int64_t ldq, mjv_bf16* k, int64_t ldk,
                         const mjv_bf16* cos_tab, const mjv_bf16* sin_tab, const int32_t* positions,
                         int32_t rows, int32_t kv_heads, int32_t group, void* stream);
+
+/* ABI 7 - rotary embedding in place on `n_heads` consecutive heads of every row (head h at x + row * ldx + h * head_stride): the
+ * language tower of BASELINE configs[4] (InternVL2-4B = InternViT + Phi-3-mini; the reference cannot build it -
+ * internvl2/modeling_internvl_chat.py:125-130 - so this restates transformers/models/phi3/modeling_phi3.py, the module the
+ * upstream checkpoint's code is generated from): apply_rotary_pos_emb on qkv_proj's [q heads | k heads | v heads] columns, one
+ * launch over the q + k heads.  x' = bf16(bf16(x cos) + bf16(rotate_half(x) sin)) on the first rot_dim elements of a head;
+ * cos / sin [positions][rot_dim] bf16 tables that already carry the LongRoPE attention factor (Phi3RotaryEmbedding.forward).
+ * rot_dim % 16 == 0, head_stride % 8 == 0, 16-byte aligned pointers. */
+int mjv_rope_heads_bf16(mjv_bf16* x, int64_t ldx, int32_t head_stride, int32_t n_heads, int32_t rot_dim, const mjv_bf16* cos_tab,
+                        const mjv_bf16* sin_tab, const int32_t* positions, int32_t rows, void* stream);
 
 /* im2col for the patch-embedding conv (modeling_intern_vit.py:145-147,164): pixels [tiles][3][S][S] ->
  * patches [tiles * (S/P)^2][ldp], column = c*P*P + i*P + j, zero-padded to ldp. */

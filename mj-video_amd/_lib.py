@@ -22,7 +22,7 @@ class MjvLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6  # MJV_ABI_VERSION of include/mjv.h
+ABI_VERSION = 7  # MJV_ABI_VERSION of include/mjv.h
 FMT_BF16, FMT_MXFP8 = 0, 1   # enum mjv_format
 
 
@@ -84,6 +84,7 @@ SYMBOLS = {
     "mjv_rmsnorm_mxfp8": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _VP, _I32, _I32, _F, _VP]),
     "mjv_row_stats_bf16": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _I32, _F, _VP]),
     "mjv_rope_split_bf16": (C.c_int, [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
+    "mjv_rope_heads_bf16": (C.c_int, [_VP, _I64, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _VP]),
     "mjv_patchify_bf16": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _VP]),
     "mjv_cls_rows_bf16": (C.c_int, [_VP, _I64, _VP, _VP, _I32, _I32, _I32, _VP]),
     "mjv_embed_gather_bf16": (C.c_int, [_VP, _VP, _I64, _VP, _I64, _I32, _I32, _I32, _I32, _VP]),
@@ -111,6 +112,7 @@ BENCH_LIB_PATH = os.path.join(_PKG_DIR, "libmjv_hip_bench.so")
 
 _lock = threading.Lock()
 _lib = None
+_lib_path = None   # realpath of the file load_library() actually opened (assert_product_library compares THIS, not the env)
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -128,7 +130,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 def load_library():
     """Loads the library once and type-checks every exported symbol.  Never falls back to anything."""
-    global _lib
+    global _lib, _lib_path
     with _lock:
         if _lib is not None:
             return _lib
@@ -158,7 +160,7 @@ def load_library():
                 fn.restype, fn.argtypes = res, args
         if lib.mjv_abi_version() != ABI_VERSION:
             raise MjvLibraryError(f"ABI version mismatch: library {lib.mjv_abi_version()} != binding {ABI_VERSION}")
-        _lib = lib
+        _lib, _lib_path = lib, os.path.realpath(path)
         return lib
 
 
@@ -174,7 +176,7 @@ def assert_product_library() -> None:
     other than the in-tree product library - the stamps build exports no bench symbol and would pass a symbol test.
     Direct ``model.forward`` calls (tools/, tests A/B-ing builds) are not policed: they choose their library on purpose."""
     load_library()
-    path = os.path.realpath(os.environ.get("MJV_LIBRARY") or LIB_PATH)
+    path = _lib_path   # the file that was opened - not what MJV_LIBRARY says now (it may have been changed after the load)
     if is_bench_build() or path != os.path.realpath(LIB_PATH):
         raise MjvLibraryError(f"a diagnostics build of the library is loaded ({path}; MJV_LIBRARY): bench / stamps builds carry "
                               "measurement switches or instrumentation and must not score; unset MJV_LIBRARY")

@@ -2,7 +2,7 @@
 
 Host-side string logic only.  Behaviour follows
 scripts/model/internvl2/modeling_internvl_chat.py:36-89 (``prepare_chat_input``) and the
-``internlm2-chat`` template of scripts/model/internvl2/conversation.py:240-249,354-365
+``internlm2-chat`` / ``phi3-chat`` templates of scripts/model/internvl2/conversation.py:240-249,354-379
 (MPT separator style: ``system + sep + (role + message + sep)* + role``).
 
 Quirk kept on purpose: callers never pass ``num_patches_list``, so it defaults
@@ -53,6 +53,9 @@ _TEMPLATES = {
                                    ("<|im_start|>user\n", "<|im_start|>assistant\n"), "<|im_end|>"),
     "Hermes-2": ChatTemplate("Hermes-2", "<|im_start|>system\n{system_message}", _SYSTEM_ZH,
                              ("<|im_start|>user\n", "<|im_start|>assistant\n"), "<|im_end|>"),
+    # conversation.py:368-379 - the template of the Phi-3 based InternVL2-4B (BASELINE configs[4])
+    "phi3-chat": ChatTemplate("phi3-chat", "<|system|>\n{system_message}", _SYSTEM_ZH,
+                              ("<|user|>\n", "<|assistant|>\n"), "<|end|>"),
 }
 
 

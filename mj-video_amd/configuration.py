@@ -5,6 +5,8 @@ rules, ``to_dict`` layout) without depending on ``transformers``:
 
 * ``InternVisionConfig``        <- scripts/model/internvl2/configuration_intern_vit.py:16-120
 * ``InternLM2Config``           <- scripts/model/internvl2/configuration_internlm2.py:27-150
+* ``Phi3Config``                <- transformers/models/phi3/configuration_phi3.py (transformers 5.15; the language model of
+                                   BASELINE configs[4]'s InternVL2-4B backbone - the reference has no Phi-3 code)
 * ``InternVLChatConfig``        <- scripts/model/internvl2/configuration_internvl_chat.py:19-96
 * ``InternVLChatRewardModelingConfig`` <- scripts/model/moe_reward.py:92-133
 
@@ -156,6 +158,75 @@ class InternLM2Config(_ConfigBase):
             raise ValueError(f"`rope_scaling`'s factor field must be a float >= 1, got {f}")
 
 
+class Phi3Config(_ConfigBase):
+    """The fields of transformers' ``Phi3Config`` the scoring path reads (transformers/models/phi3/configuration_phi3.py,
+    transformers 5.15).  ``rope_scaling`` = None or the LongRoPE dict {"type": "longrope" | "su", "short_factor": [...],
+    "long_factor": [...]} (+ optional "factor" / "attention_factor"), lists of head_dim * partial_rotary_factor / 2 floats; the
+    newer ``rope_parameters`` spelling is accepted and folded into the same fields."""
+    model_type = "phi3"
+
+    def __init__(self, vocab_size=32064, hidden_size=3072, intermediate_size=8192, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=None, resid_pdrop=0.0, embd_pdrop=0.0, attention_dropout=0.0,
+                 hidden_act="silu", max_position_embeddings=4096, original_max_position_embeddings=4096,
+                 initializer_range=0.02, rms_norm_eps=1e-5, use_cache=True, tie_word_embeddings=False, rope_theta=10000.0,
+                 rope_scaling=None, partial_rotary_factor=1.0, bos_token_id=1, eos_token_id=32000, pad_token_id=32000,
+                 sliding_window=None, attn_implementation="eager", **kwargs):
+        rp = kwargs.pop("rope_parameters", None)
+        if rp:   # transformers >= 5 spelling
+            rp = copy.deepcopy(rp)
+            rope_theta = rp.pop("rope_theta", rope_theta)
+            partial_rotary_factor = rp.pop("partial_rotary_factor", partial_rotary_factor)
+            original_max_position_embeddings = rp.pop("original_max_position_embeddings", original_max_position_embeddings)
+            kind = rp.pop("rope_type", rp.pop("type", "default"))
+            if kind != "default":
+                rope_scaling = dict(rp, type=kind)
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.num_key_value_heads = num_attention_heads if num_key_value_heads is None else num_key_value_heads
+        self.resid_pdrop = resid_pdrop
+        self.embd_pdrop = embd_pdrop
+        self.attention_dropout = attention_dropout
+        self.hidden_act = hidden_act
+        self.max_position_embeddings = max_position_embeddings
+        self.original_max_position_embeddings = original_max_position_embeddings
+        self.initializer_range = initializer_range
+        self.rms_norm_eps = rms_norm_eps
+        self.use_cache = use_cache
+        self.rope_theta = rope_theta
+        self.rope_scaling = copy.deepcopy(rope_scaling)
+        self.partial_rotary_factor = partial_rotary_factor
+        self._rope_scaling_validation()
+        self.sliding_window = sliding_window
+        self.attn_implementation = attn_implementation or "eager"
+        self.pad_token_id = pad_token_id
+        self.bos_token_id = bos_token_id
+        self.eos_token_id = eos_token_id
+        self.tie_word_embeddings = tie_word_embeddings
+        self._init_common(kwargs)
+
+    def _rope_scaling_validation(self):
+        """configuration_phi3.py: the two factor lists must hold rotary_dim / 2 numbers each"""
+        rs = self.rope_scaling
+        if rs is None:
+            return
+        if not isinstance(rs, dict) or rs.get("type", rs.get("rope_type")) not in ("longrope", "su", "yarn"):
+            raise ValueError(f"`rope_scaling` must be a LongRoPE dictionary (type 'longrope' / 'su'), got {rs}")
+        if rs.get("type", rs.get("rope_type")) == "yarn":
+            raise NotImplementedError("Phi-3 with yarn rope scaling is not built (InternVL2-4B's Phi-3-mini uses LongRoPE)")
+        rs["type"] = "longrope"
+        rs.pop("rope_type", None)
+        n = int(self.hidden_size // self.num_attention_heads * self.partial_rotary_factor) // 2
+        for key in ("short_factor", "long_factor"):
+            f = rs.get(key)
+            if not isinstance(f, (list, tuple)) or not all(isinstance(v, (int, float)) for v in f):
+                raise ValueError(f"`rope_scaling`'s {key} field must be a list of numbers, got {f}")
+            if len(f) != n:
+                raise ValueError(f"`rope_scaling`'s {key} field must have length {n}, got {len(f)}")
+
+
 class InternVLChatConfig(_ConfigBase):
     model_type = "internvl_chat"
     is_composition = True
@@ -169,12 +240,16 @@ class InternVLChatConfig(_ConfigBase):
             llm_config = {}
         if isinstance(vision_config, InternVisionConfig):
             vision_config = vision_config.to_dict()
-        if isinstance(llm_config, InternLM2Config):
+        if isinstance(llm_config, (InternLM2Config, Phi3Config)):
             llm_config = llm_config.to_dict()
         self.vision_config = InternVisionConfig(**copy.deepcopy(vision_config))
         arch = (llm_config.get("architectures") or [None])[0]
         if arch == "InternLM2ForCausalLM":
             self.llm_config = InternLM2Config(**copy.deepcopy(llm_config))
+        elif arch == "Phi3ForCausalLM":
+            # not in the reference's dispatch (configuration_internvl_chat.py:50-55: Llama / InternLM2): the upstream InternVL2-4B
+            # config adds exactly this branch; BASELINE configs[4] names that backbone
+            self.llm_config = Phi3Config(**copy.deepcopy(llm_config))
         else:
             # configuration_internvl_chat.py:50-55 also admits LlamaForCausalLM; MJ-VIDEO-2B is InternLM2 only.
             raise ValueError("Unsupported architecture: {}".format(arch))
@@ -209,6 +284,8 @@ class InternVLChatRewardModelingConfig(InternVLChatConfig):
 
     _HEAD_FIELDS = ("num_objectives", "num_aspects", "aspect2criteria", "gating_temperature",
                     "gating_hidden_dim", "gating_n_hidden")
+    # `<|im_end|><|im_start|>assistant\n` in InternLM2 token ids: the module constant of moe_reward.py:45-48
+    INTERNLM2_GATING_PATTERN = (92542, 92543, 525, 11353, 364)
 
     def __init__(self, internVLChatConfigName_or_path=None, **kwargs):
         head = {k: kwargs.pop(k) for k in self._HEAD_FIELDS if k in kwargs}
@@ -219,6 +296,12 @@ class InternVLChatRewardModelingConfig(InternVLChatConfig):
         self.gating_temperature = head.get("gating_temperature", 1.0)
         self.gating_hidden_dim = head.get("gating_hidden_dim", 1024)
         self.gating_n_hidden = head.get("gating_n_hidden", 3)
+        # the token ids whose LAST occurrence marks the gating row (end of the user turn + the assistant header).  The
+        # reference hard-codes the InternLM2 tokenizer's ids (moe_reward.py:45-48); a config field here (not one of the
+        # reference's: it rides in kwargs / config.json) because the Phi-3 backbone of configs[4] has another tokenizer.
+        if not hasattr(self, "gating_token_pattern") or self.gating_token_pattern is None:
+            self.gating_token_pattern = list(self.INTERNLM2_GATING_PATTERN)
+        self.gating_token_pattern = [int(t) for t in self.gating_token_pattern]
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
@@ -256,6 +339,54 @@ def mjvideo_2b_config_dict(image_size: int = 448) -> Dict[str, Any]:
         select_layer=-1, force_image_size=image_size, downsample_ratio=0.5, template="internlm2-chat",
         dynamic_image_size=True, use_thumbnail=True, ps_version="v2", min_dynamic_patch=1, max_dynamic_patch=12,
     )
+
+
+# stand-in special-token ids of the InternVL2-4B (Phi-3) tokenizer [recalled, unpinned: no tokenizer offline]: `<|end|>` 32007,
+# `<|assistant|>` 32001, "\n" 13 - the phi3-chat template's counterpart of `<|im_end|><|im_start|>assistant\n`
+# (conversation.py:368-379: roles ('<|user|>\n', '<|assistant|>\n'), sep '<|end|>')
+PHI3_GATING_PATTERN = (32007, 32001, 13)
+
+
+def longrope_factors(n: int, seed: int = 0):
+    """Seed-defined stand-ins for a checkpoint's LongRoPE factor lists (the real lists of Phi-3-mini-128k are in its config.json,
+    not available offline): ``n`` short factors rising from 1.0 to about 2.8 and long factors rising from 1.0 to about 64, the
+    shape of the published ones (low frequencies are stretched more)."""
+    import numpy as np
+    g = np.random.Generator(np.random.Philox(key=[seed, 0x10A6]))
+    t = np.linspace(0.0, 1.0, n)
+    short = 1.0 + 1.8 * t ** 2 + 0.05 * g.random(n)
+    long = np.exp(np.log(64.0) * t ** 1.5) + 0.05 * g.random(n)
+    return [float(np.float32(v)) for v in short], [float(np.float32(v)) for v in long]
+
+
+def internvl2_4b_config_dict(image_size: int = 448) -> Dict[str, Any]:
+    """The InternVL2-4B architecture of BASELINE configs[4]: the vision tower of the 2B model (InternViT-300M-448px) + a
+    Phi-3-mini-128k decoder (hidden 3072, 32 heads x 96, MHA, ff 8192, 32 layers, LongRoPE 4096 -> 131072) [recalled: published
+    dimensions; the checkpoint's config.json, factor lists and tokenizer are not available offline]."""
+    d = mjvideo_2b_config_dict(image_size)
+    short, long = longrope_factors(48)
+    d["llm_config"] = dict(
+        architectures=["Phi3ForCausalLM"], vocab_size=32020, hidden_size=3072, intermediate_size=8192, num_hidden_layers=32,
+        num_attention_heads=32, num_key_value_heads=32, hidden_act="silu", max_position_embeddings=131072,
+        original_max_position_embeddings=4096, initializer_range=0.02, rms_norm_eps=1e-5, use_cache=True,
+        rope_theta=10000.0, rope_scaling={"type": "longrope", "short_factor": short, "long_factor": long},
+        bos_token_id=1, eos_token_id=32000, pad_token_id=32000, sliding_window=262144, tie_word_embeddings=False,
+        attn_implementation="eager")
+    d["template"] = "phi3-chat"
+    d["gating_token_pattern"] = list(PHI3_GATING_PATTERN)
+    return d
+
+
+def tiny_phi3_config_dict(image_size: int = 56) -> Dict[str, Any]:
+    """``tiny_config_dict`` with a two-layer Phi-3 decoder (2 heads x 96, MHA; LongRoPE with a 64-position original window so that
+    BOTH factor lists are exercised by sequences of a few hundred tokens)."""
+    d = internvl2_4b_config_dict(image_size)
+    d["vision_config"].update(hidden_size=128, num_attention_heads=2, intermediate_size=512, num_hidden_layers=2,
+                              image_size=image_size)
+    d["llm_config"].update(hidden_size=192, num_attention_heads=2, num_key_value_heads=2, intermediate_size=512,
+                           num_hidden_layers=2, max_position_embeddings=4096, original_max_position_embeddings=128)
+    d["force_image_size"] = image_size
+    return d
 
 
 DEFAULT_ASPECT2CRITERIA = {

@@ -631,16 +631,30 @@ __device__ unsigned long long* g_stamp_out = nullptr;
 #define MJV_STAMP(i) do { } while (0)
 #endif
 
-// NSUB = 32-query sub-blocks per wave: 2 at D = 64; 1 at D = 128, where two would need ~310 registers (the pipeline then
+// Chunk swizzles of the unpadded LDS image (16-byte chunk c of row r sits at chunk c ^ swz(r)), per head size.  D = 64 / 128: as
+// attn_kernel<.., DMA = true>.  D = 96 (ABI 7, Phi-3-mini's heads): rows are 192 bytes = 12 chunks, so the XOR may only touch
+// the two low bits of the chunk index: K swz = (r >> 2) & 3 - the 16 lanes of a ds_read_b128 group (rows {0-3, 12-15, 20-27} /
+// {4-11, 16-19, 28-31}) differ in (r mod 4, (r >> 2) & 3), and slot mod 16 = 4 (3 r mod 4) + (c & 12) + ((c & 3) ^ swz): all
+// distinct; V needs none - four consecutive rows of 48 banks start at banks 0, 48, 32, 16, the 16-bank windows a
+// ds_read_b64_tr_b16 half-wave reads from them tile the 64 banks.
+template <int D>
+MJV_DEV constexpr int swz_k(int row) { return D == 64 ? ((row >> 1) & 7) : (D == 128 ? (row & 15) : ((row >> 2) & 3)); }
+template <int D>
+MJV_DEV constexpr int swz_v(int row) { return D == 64 ? (((row >> 1) & 1) * 4) : (D == 128 ? ((row & 3) * 4) : 0); }
+constexpr int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// NSUB = 32-query sub-blocks per wave: 2 at D = 64; 1 at D = 128 / 96, where two would need ~310 registers (the pipeline then
 // runs over the two key halves of the one sub-block: QK(h0) | QK(h1) || softmax(h0) | PV(h0) || softmax(h1) | PV(h1))
 template <int D, bool CAUSAL, int RM, int NW, int NSUB>
 __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   constexpr int PK = D * 2, PV = D * 2;           // unpadded rows, swizzled chunks (as the DMA form of attn_kernel)
-  constexpr int KBYTES = KB * PK, VBYTES = KB * PV, TB = KBYTES + VBYTES;
+  // TB = distance of the two tile buffers: a power of two (the buffer toggle XORs it into the fragment offsets); at D = 96 the
+  // 24 KiB of a tile sit in a 32 KiB slot
+  constexpr int KBYTES = KB * PK, VBYTES = KB * PV, TB = pow2_ceil(KBYTES + VBYTES);
   constexpr int QW = 32 * NSUB;                   // queries per wave
   constexpr int QBW = QW * NW;                    // queries per workgroup
   constexpr int F = D / 16;                       // MFMAs per unit and product
-  static_assert((TB & (TB - 1)) == 0, "the buffer toggle XORs TB into the fragment offsets");
+  static_assert((TB & (TB - 1)) == 0 && TB >= KBYTES + VBYTES, "the buffer toggle XORs TB into the fragment offsets");
   __shared__ __attribute__((aligned(16))) char smem[2 * TB];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -772,8 +786,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   for (int j = 0; j < NI; ++j) {
     const int slot = (j * NW + wave) * 64 + lane;
     const int row = slot / CH, cl = slot % CH;
-    const int sk = (D == 64) ? ((row >> 1) & 7) : (row & 15);
-    const int sv = (D == 64) ? (((row >> 1) & 1) * 4) : ((row & 3) * 4);
+    const int sk = swz_k<D>(row);
+    const int sv = swz_v<D>(row);
     kso[j] = (unsigned)(row * (int)p.ldk + ((cl ^ sk) * 8)) * 2u;
     vso[j] = (unsigned)(row * (int)p.ldv + ((cl ^ sv) * 8)) * 2u;
   }
@@ -801,7 +815,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
     } else {
       const int slot = (j * NW + wave) * 64 + lane;
       const int row = slot / CH, cl = slot % CH;
-      const int sw = is_v ? ((D == 64) ? (((row >> 1) & 1) * 4) : ((row & 3) * 4)) : ((D == 64) ? ((row >> 1) & 7) : (row & 15));
+      const int sw = is_v ? swz_v<D>(row) : swz_k<D>(row);
       int gr = kt * KB + row;
       gr = gr < klen ? gr : klen - 1;                   // rows past the end: any valid row (masked later)
       off = (unsigned)(gr * (int)(is_v ? p.ldv : p.ldk) + ((cl ^ sw) * 8)) * 2u;
@@ -822,11 +836,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn2_kernel(AttnArgs p) {
   // per-lane LDS byte offsets of the fragments (the swizzle terms are lane constants)
   int koff[F], vboff[D / 32];
   {
-    const int ksw = (D == 64) ? ((l31 >> 1) & 7) : (l31 & 15);
+    const int ksw = swz_k<D>(l31);
 #pragma unroll
     for (int ks = 0; ks < F; ++ks) koff[ks] = l31 * PK + (((hi + 2 * ks) ^ ksw) << 4);
     const int li = lane & 15, g16 = (lane >> 4) & 1, trow = li >> 2, tcol = 4 * (li & 3);
-    const int svl = (D == 64) ? (((trow >> 1) & 1) * 4) : (trow * 4);
+    const int svl = swz_v<D>(trow);     // (rows 4 hi + trow + 8 k: the V swizzles depend on the row's two low bits only)
 #pragma unroll
     for (int g = 0; g < D / 32; ++g)
       vboff[g] = (4 * hi + trow) * PV + (((g * 4 + g16 * 2 + (tcol >> 3)) ^ svl) << 4) + (tcol & 7) * 2;
@@ -1166,9 +1180,9 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
     // two-wave block would leave ONE wave per SIMD (the compiler said so for every such instantiation: "desired occupancy was
     // 2, final occupancy is 1") - refused instead of run at half occupancy
     const bool small = kernel == 6;
-    if constexpr (D == 128) {
+    if constexpr (D != 64) {
       if (small) {
-        mjv_set_error("attention: kernel 6 (two waves per workgroup) exists for head_dim 64 only - at head_dim 128 the 64 KiB of "
+        mjv_set_error("attention: kernel 6 (two waves per workgroup) exists for head_dim 64 only - at head_dim 96 / 128 the 64 KiB of "
                       "staged K / V per workgroup would leave one wave per SIMD; use kernel 0 / 7");
         return MJV_E_UNSUPPORTED;
       }
@@ -1179,6 +1193,10 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
     }
     return mjv_check_launch("attention");
   }
+  if constexpr (D == 96) {   // (ABI 7: head_dim 96 exists in the round-3 kernel only)
+    mjv_set_error("attention: head_dim 96 runs on the round-3 kernel only (kernel 0 / 7)");
+    return MJV_E_UNSUPPORTED;
+  } else {
   // LDS-DMA staging up to 4096 keys per sequence (measured +2 ... +3 % at 1025 / 2186, 0 at 2048 non-causal); beyond that
   // the register-staged form is the faster one (causal, 8192 keys: 0.64 vs 0.66 ms), so the long-context config keeps it
   if (a.round_mode == 1) {
@@ -1192,6 +1210,7 @@ int launch(AttnArgs a, int n_seqs, int max_seqlen, int kernel, hipStream_t s) {
     else hipLaunchKernelGGL((attn_kernel<D, CAUSAL, RM_MUL, 0, false>), grid, dim3(256), 0, s, a);
   }
   return mjv_check_launch("attention");
+  }
 }
 
 }  // namespace
@@ -1218,7 +1237,7 @@ extern "C" int mjv_bench_attention_set(int32_t v) {
 
 extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
   MJV_REQUIRE(d && d->Q && d->K && d->V && d->O && d->cu_seqlens, "attention: null pointer");
-  MJV_REQUIRE(d->head_dim == 64 || d->head_dim == 128, "attention: head_dim %d not in {64,128}", d->head_dim);
+  MJV_REQUIRE(d->head_dim == 64 || d->head_dim == 96 || d->head_dim == 128, "attention: head_dim %d not in {64, 96, 128}", d->head_dim);
   MJV_REQUIRE(d->kernel == 0 || (d->kernel >= 4 && d->kernel <= 7), "attention: kernel %d not in {0, 4, 5, 6, 7}", d->kernel);
   MJV_REQUIRE(d->score_round_mode >= 0 && d->score_round_mode <= 2, "attention: score_round_mode %d not in {0, 1, 2}", d->score_round_mode);
   MJV_REQUIRE(d->score_round_mode != 2 || (d->kernel != 4 && d->kernel != 5),
@@ -1267,6 +1286,11 @@ extern "C" int mjv_attention_bf16(const mjv_attn_desc* d, void* stream) {
     if (d->causal) { MjvProfScope ps("attn_d64_causal", s, flops, 0); return launch<64, true>(a, d->n_seqs, max_q, d->kernel, s); }
     MjvProfScope ps("attn_d64", s, flops, 0);
     return launch<64, false>(a, d->n_seqs, d->max_seqlen, d->kernel, s);
+  }
+  if (d->head_dim == 96) {
+    if (d->causal) { MjvProfScope ps("attn_d96_causal", s, flops, 0); return launch<96, true>(a, d->n_seqs, max_q, d->kernel, s); }
+    MjvProfScope ps("attn_d96", s, flops, 0);
+    return launch<96, false>(a, d->n_seqs, d->max_seqlen, d->kernel, s);
   }
   if (d->causal) { MjvProfScope ps("attn_d128_causal", s, flops, 0); return launch<128, true>(a, d->n_seqs, max_q, d->kernel, s); }
   MjvProfScope ps("attn_d128", s, flops, 0);

@@ -228,6 +228,40 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const u16* __restrict__
   *(u32x4*)(dst + d + 64) = pack8(o2);
 }
 
+// Rotary embedding IN PLACE on n_heads consecutive heads of every row (the Phi-3 layout of BASELINE configs[4]'s language
+// tower: qkv_proj's columns are [q heads | k heads | v heads], so ONE launch over the first q + k heads rotates both):
+// x' = bf16(bf16(x cos) + bf16(rotate_half(x) sin)) on the first rot_dim elements of a head, bf16 tables [positions][rot_dim]
+// that already carry the LongRoPE attention factor (transformers/models/phi3/modeling_phi3.py: apply_rotary_pos_emb,
+// Phi3RotaryEmbedding.forward).  One thread: 8 elements j..j+7 of the first half and their partners j + rot_dim / 2.
+__global__ __launch_bounds__(256) void rope_heads_kernel(u16* __restrict__ x, long ldx, int head_stride, int n_heads, int rot_dim,
+                                                         const u16* __restrict__ cos_tab, const u16* __restrict__ sin_tab,
+                                                         const int* __restrict__ positions, int rows) {
+  const int half = rot_dim >> 1, cph = half >> 3;   // 16-byte chunks per half
+  const long total = (long)rows * n_heads * cph;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int d = (int)(gid % cph) * 8;
+  const long rh = gid / cph;
+  const int head = (int)(rh % n_heads);
+  const long row = rh / n_heads;
+  u16* p = x + row * ldx + (long)head * head_stride;
+  const long pos = positions[row];
+  float x1[8], x2[8], c1[8], c2[8], s1[8], s2[8], o1[8], o2[8];
+  unpack8(*(const u32x4*)(p + d), x1);
+  unpack8(*(const u32x4*)(p + d + half), x2);
+  unpack8(*(const u32x4*)(cos_tab + pos * rot_dim + d), c1);
+  unpack8(*(const u32x4*)(cos_tab + pos * rot_dim + d + half), c2);
+  unpack8(*(const u32x4*)(sin_tab + pos * rot_dim + d), s1);
+  unpack8(*(const u32x4*)(sin_tab + pos * rot_dim + d + half), s2);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    o1[j] = rbf(x1[j] * c1[j]) + rbf(-x2[j] * s1[j]);
+    o2[j] = rbf(x2[j] * c2[j]) + rbf(x1[j] * s2[j]);
+  }
+  *(u32x4*)(p + d) = pack8(o1);
+  *(u32x4*)(p + d + half) = pack8(o2);
+}
+
 // --------------------------------------------------------------------------------------------- patchify
 // patches[tile*G*G + a*G + b][c*P*P + i*P + j] = pixels[tile][c][a*P + i][b*P + j]; columns >= 3*P*P are zero.
 __global__ __launch_bounds__(256) void patchify_kernel(const u16* __restrict__ px, u16* __restrict__ out, long ldp, int tiles,
@@ -453,6 +487,22 @@ extern "C" int mjv_rope_split_bf16(const mjv_bf16* qkv, int64_t ldqkv, mjv_bf16*
   hipLaunchKernelGGL(rope_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, (long)ldqkv, q, (long)ldq,
                      k, (long)ldk, cos_tab, sin_tab, positions, rows, kv_heads, group);
   return mjv_check_launch("rope_split");
+}
+
+extern "C" int mjv_rope_heads_bf16(mjv_bf16* x, int64_t ldx, int32_t head_stride, int32_t n_heads, int32_t rot_dim,
+                                   const mjv_bf16* cos_tab, const mjv_bf16* sin_tab, const int32_t* positions, int32_t rows,
+                                   void* stream) {
+  MJV_REQUIRE(x && cos_tab && sin_tab && positions, "rope_heads: null pointer");
+  MJV_REQUIRE(rows > 0 && n_heads > 0 && rot_dim > 0 && rot_dim % 16 == 0 && rot_dim <= head_stride,
+              "rope_heads: rot_dim %d must be a positive multiple of 16 within the head stride %d", rot_dim, head_stride);
+  MJV_REQUIRE(ldx % 8 == 0 && head_stride % 8 == 0 && ((uintptr_t)x | (uintptr_t)cos_tab | (uintptr_t)sin_tab) % 16 == 0,
+              "rope_heads: alignment (16-byte pieces of a head)");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)rows * n_heads * (rot_dim / 16);
+  MjvProfScope ps("rope_heads", s, 0, 4.0 * rows * (double)n_heads * rot_dim);
+  hipLaunchKernelGGL(rope_heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, (long)ldx, head_stride, n_heads,
+                     rot_dim, cos_tab, sin_tab, positions, rows);
+  return mjv_check_launch("rope_heads");
 }
 
 extern "C" int mjv_patchify_bf16(const mjv_bf16* pixels, mjv_bf16* patches, int64_t ldp, int32_t tiles, int32_t image_size,

@@ -351,6 +351,19 @@ def rope_split(qkv: torch.Tensor, q: torch.Tensor, k: torch.Tensor, cos: torch.T
                                       qkv.shape[0], kv_heads, group, _stream(qkv)), "mjv_rope_split_bf16")
 
 
+def rope_heads(x: torch.Tensor, n_heads: int, head_stride: int, cos: torch.Tensor, sin: torch.Tensor,
+               positions: torch.Tensor) -> None:
+    """Rotary embedding IN PLACE on the first ``n_heads`` heads (``head_stride`` elements apart, from column 0) of every row of
+    ``x``; ``cos`` / ``sin`` [positions, rot_dim] bf16 tables (include/mjv.h, ABI 7: the Phi-3 tower's [q | k | v] projection)."""
+    _chk_bf16(x, cos, sin)
+    assert positions.dtype == torch.int32 and positions.is_cuda and positions.numel() >= x.shape[0]
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.shape == sin.shape
+    assert n_heads * head_stride <= x.shape[1]
+    with torch.cuda.device(x.device):
+        check(load_library().mjv_rope_heads_bf16(x.data_ptr(), _row_stride(x), head_stride, n_heads, cos.shape[1], cos.data_ptr(),
+                                                 sin.data_ptr(), positions.data_ptr(), x.shape[0], _stream(x)), "mjv_rope_heads_bf16")
+
+
 def patchify(pixels: torch.Tensor, patches: torch.Tensor, patch: int) -> torch.Tensor:
     _chk_bf16(pixels, patches)
     assert pixels.is_contiguous() and pixels.dim() == 4 and pixels.shape[1] == 3 and pixels.shape[2] == pixels.shape[3]

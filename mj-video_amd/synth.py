@@ -24,6 +24,29 @@ GATING_PATTERN = (92542, 92543, 525, 11353, 364)
 N_TEXT_TOKENS = 138  # non-image tokens of the synthetic prompt (N = 2186 at 8x256 image tokens)
 
 
+class TokenProfile:
+    """the special-token ids a synthetic prompt is built from (one per tokenizer family)"""
+
+    def __init__(self, name, im_end, im_start, img_start, img_end, img_context, bos, pad, nl, gating_pattern, text_hi):
+        self.name, self.im_end, self.im_start = name, im_end, im_start
+        self.img_start, self.img_end, self.img_context = img_start, img_end, img_context
+        self.bos, self.pad, self.nl, self.gating_pattern, self.text_hi = bos, pad, nl, tuple(gating_pattern), text_hi
+
+
+INTERNLM2_TOKENS = TokenProfile("internlm2", IM_END, IM_START, IMG_START_ID, IMG_END_ID, IMG_CONTEXT_ID, BOS_ID, PAD_ID, 364,
+                                GATING_PATTERN, 60000)
+# stand-in ids of the InternVL2-4B (Phi-3) tokenizer [recalled, unpinned - no tokenizer offline]: `<|end|>` 32007 closes a turn,
+# `<|system|>` 32006 / `<|user|>` 32010 / `<|assistant|>` 32001 open one, `<img>` 32011, `</img>` 32012, `<IMG_CONTEXT>` 32013,
+# pad = `<|endoftext|>` 32000; the gating pattern is `<|end|><|assistant|>\n` (configuration.PHI3_GATING_PATTERN).  The same
+# prompt STRUCTURE as the InternLM2 profile (same positions of every run), so sequence lengths match: im_start stands for the
+# role marker of a turn.
+PHI3_TOKENS = TokenProfile("phi3", 32007, 32010, 32011, 32012, 32013, 1, 32000, 13, (32007, 32001, 13), 30000)
+
+
+def token_profile(config) -> TokenProfile:
+    return PHI3_TOKENS if type(config.llm_config).__name__ == "Phi3Config" else INTERNLM2_TOKENS
+
+
 def _rng(seed: int, name: str) -> np.random.Generator:
     return np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())]))
 
@@ -63,15 +86,26 @@ def state_dict_spec(config) -> List[Tuple[str, Tuple[int, ...], str]]:
     h, lf = l.hidden_size, l.intermediate_size
     hd = h // l.num_attention_heads
     qkv_out = (l.num_attention_heads + 2 * l.num_key_value_heads) * hd
-    spec.append(("model.language_model.model.tok_embeddings.weight", (l.vocab_size, h), "w"))
-    for i in range(l.num_hidden_layers):
-        p = f"model.language_model.model.layers.{i}."
-        spec += [(p + "attention.wqkv.weight", (qkv_out, h), "w"), (p + "attention.wo.weight", (h, h), "w"),
-                 (p + "feed_forward.w1.weight", (lf, h), "w"), (p + "feed_forward.w3.weight", (lf, h), "w"),
-                 (p + "feed_forward.w2.weight", (h, lf), "w"),
-                 (p + "attention_norm.weight", (h,), "g"), (p + "ffn_norm.weight", (h,), "g")]
-    spec.append(("model.language_model.model.norm.weight", (h,), "g"))
-    spec.append(("model.language_model.output.weight", (l.vocab_size, h), "lmhead"))
+    if type(l).__name__ == "Phi3Config":   # transformers/models/phi3/modeling_phi3.py parameter names (the upstream 4B checkpoint's)
+        spec.append(("model.language_model.model.embed_tokens.weight", (l.vocab_size, h), "w"))
+        for i in range(l.num_hidden_layers):
+            p = f"model.language_model.model.layers.{i}."
+            spec += [(p + "self_attn.o_proj.weight", (h, l.num_attention_heads * hd), "w"),
+                     (p + "self_attn.qkv_proj.weight", (qkv_out, h), "w"),
+                     (p + "mlp.gate_up_proj.weight", (2 * lf, h), "w"), (p + "mlp.down_proj.weight", (h, lf), "w"),
+                     (p + "input_layernorm.weight", (h,), "g"), (p + "post_attention_layernorm.weight", (h,), "g")]
+        spec.append(("model.language_model.model.norm.weight", (h,), "g"))
+        spec.append(("model.language_model.lm_head.weight", (l.vocab_size, h), "lmhead"))
+    else:
+        spec.append(("model.language_model.model.tok_embeddings.weight", (l.vocab_size, h), "w"))
+        for i in range(l.num_hidden_layers):
+            p = f"model.language_model.model.layers.{i}."
+            spec += [(p + "attention.wqkv.weight", (qkv_out, h), "w"), (p + "attention.wo.weight", (h, h), "w"),
+                     (p + "feed_forward.w1.weight", (lf, h), "w"), (p + "feed_forward.w3.weight", (lf, h), "w"),
+                     (p + "feed_forward.w2.weight", (h, lf), "w"),
+                     (p + "attention_norm.weight", (h,), "g"), (p + "ffn_norm.weight", (h,), "g")]
+        spec.append(("model.language_model.model.norm.weight", (h,), "g"))
+        spec.append(("model.language_model.output.weight", (l.vocab_size, h), "lmhead"))
     c4 = d * int(1 / config.downsample_ratio) ** 2
     spec += [("model.mlp1.0.weight", (c4,), "g"), ("model.mlp1.0.bias", (c4,), "b"),
              ("model.mlp1.1.weight", (h, c4), "w"), ("model.mlp1.1.bias", (h,), "b"),
@@ -198,7 +232,7 @@ def synth_pixel_values(seed: int, video_idx: int, n_tiles: int, image_size: int,
 
 
 def synth_input_ids(n_image_tokens: int, caption_seed: int, n_caption: int = 32,
-                    interleave_frames: Optional[int] = None) -> torch.Tensor:
+                    interleave_frames: Optional[int] = None, tokens: Optional[TokenProfile] = None) -> torch.Tensor:
     """Token ids with the structure of a tokenised MJ-VIDEO prompt: ``[1, n_image_tokens + 138]``.
 
     ``BOS, <|im_start|> + 61 system ids + <|im_end|>, <|im_start|> user\\n "Frame1: " <img>,
@@ -207,13 +241,15 @@ def synth_input_ids(n_image_tokens: int, caption_seed: int, n_caption: int = 32,
     behaviour.  With ``interleave_frames=F`` the image run is split into F runs,
     one per "FrameK: <img>...</img>\\n" (what ``num_patches_list=[1]*F`` produces).
     """
+    tk = INTERNLM2_TOKENS if tokens is None else tokens     # (``tokens``: another tokenizer family's special ids, same structure)
     fixed = _rng(0, "prompt-fixed")
-    sys_ids = fixed.integers(1000, 60000, size=61).tolist()
-    user_ids = fixed.integers(1000, 60000, size=2).tolist()
-    frame_ids = fixed.integers(1000, 60000, size=(8, 3)).tolist()
-    nl_id = 364
-    cap = _rng(caption_seed, "caption").integers(1000, 60000, size=n_caption).tolist()
-    ids = [BOS_ID, IM_START] + sys_ids + [IM_END, IM_START] + user_ids
+    sys_ids = fixed.integers(1000, tk.text_hi, size=61).tolist()
+    user_ids = fixed.integers(1000, tk.text_hi, size=2).tolist()
+    frame_ids = fixed.integers(1000, tk.text_hi, size=(8, 3)).tolist()
+    nl_id = tk.nl
+    IMG_START_ID, IMG_END_ID, IMG_CONTEXT_ID = tk.img_start, tk.img_end, tk.img_context
+    cap = _rng(caption_seed, "caption").integers(1000, tk.text_hi, size=n_caption).tolist()
+    ids = [tk.bos, tk.im_start] + sys_ids + [tk.im_end, tk.im_start] + user_ids
     if interleave_frames:
         F = interleave_frames
         assert n_image_tokens % F == 0 and F <= 8
@@ -223,15 +259,15 @@ def synth_input_ids(n_image_tokens: int, caption_seed: int, n_caption: int = 32,
             body += frame_ids[k] + [IMG_START_ID] + [IMG_CONTEXT_ID] * per + [IMG_END_ID, nl_id]
         # keep the total length identical to the contiguous layout: 7 literal frames <-> 7*(3+1+2-2)
         filler = 7 * 4 + 3 + 1 + 2 - F * 6
-        ids += body + (fixed.integers(1000, 60000, size=max(filler, 0)).tolist())
+        ids += body + (fixed.integers(1000, tk.text_hi, size=max(filler, 0)).tolist())
     else:
         ids += frame_ids[0] + [IMG_START_ID] + [IMG_CONTEXT_ID] * n_image_tokens + [IMG_END_ID, nl_id]
         for k in range(1, 8):
             ids += frame_ids[k] + [nl_id]
-    ids += cap + list(GATING_PATTERN)
+    ids += cap + list(tk.gating_pattern)
     t = torch.tensor(ids, dtype=torch.long).unsqueeze(0)
     if not interleave_frames:
-        assert t.shape[1] == n_image_tokens + N_TEXT_TOKENS - 32 + n_caption, t.shape
+        assert t.shape[1] == n_image_tokens + N_TEXT_TOKENS - 32 + n_caption - (5 - len(tk.gating_pattern)), t.shape
     return t
 
 
