@@ -689,7 +689,10 @@ class InternVLChatRewardModeling(nn.Module):
         Phi3RotaryEmbedding.forward for position_ids = arange(seq_len) (the reference passes none, modeling_internvl_chat.py:190-199):
         fp32 pos x inv_freq, cat(freqs, freqs), cos / sin times the LongRoPE attention factor, cast.  inv_freq takes the LONG
         factor list when the padded width ``seq_len`` exceeds original_max_position_embeddings, the SHORT one otherwise
-        (modeling_rope_utils.py: longrope_frequency_update - decided per forward, nothing kept between forwards)."""
+        (modeling_rope_utils.py: longrope_frequency_update - decided per forward, nothing kept between forwards).  The short and
+        the unscaled frequencies are ROUNDED TO BF16 first: they live in module buffers that the reference driver's
+        ``model.to(torch.bfloat16)`` casts (eval_genai_mjvideo.py:112-116; this model only runs in bf16); the long ones are
+        recomputed in fp32 inside the forward and are not."""
         lc = self.config.llm_config
         dim = int((lc.hidden_size // lc.num_attention_heads) * lc.partial_rotary_factor)
         rs = lc.rope_scaling
@@ -702,6 +705,8 @@ class InternVLChatRewardModeling(nn.Module):
         if rs:
             ext = torch.tensor(rs["long_factor"] if use_long else rs["short_factor"], dtype=torch.float32)
             inv_freq = 1.0 / (ext * float(lc.rope_theta) ** shape)
+            if not use_long:
+                inv_freq = inv_freq.to(BF16).float()
             factor = rs.get("factor")
             if factor is None:
                 factor = lc.max_position_embeddings / lc.original_max_position_embeddings
@@ -709,7 +714,7 @@ class InternVLChatRewardModeling(nn.Module):
             if att is None:
                 att = 1.0 if factor <= 1.0 else math.sqrt(1 + math.log(factor) / math.log(lc.original_max_position_embeddings))
         else:
-            inv_freq, att = 1.0 / (float(lc.rope_theta) ** shape), 1.0
+            inv_freq, att = (1.0 / (float(lc.rope_theta) ** shape)).to(BF16).float(), 1.0
         pos = torch.arange(n, dtype=torch.float32)
         freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]
         emb = torch.cat((freqs, freqs), dim=-1)

@@ -54,24 +54,31 @@ def attention_factor(l) -> float:
     return 1.0 if factor <= 1.0 else math.sqrt(1 + math.log(factor) / math.log(orig))
 
 
-def inv_freq(l, seq_len: int) -> torch.Tensor:
+def inv_freq(l, seq_len: int, dtype=torch.float32) -> torch.Tensor:
     """modeling_phi3.py:Phi3RotaryEmbedding.compute_default_rope_parameters / modeling_rope_utils.py:_compute_longrope_parameters +
     longrope_frequency_update: the LONG factors when the (padded) sequence is longer than original_max_position_embeddings,
-    the SHORT ones otherwise - chosen per forward from ``max(position_ids) + 1``, no state kept between forwards."""
+    the SHORT ones otherwise - chosen per forward from ``max(position_ids) + 1``, no state kept between forwards.
+
+    ``dtype`` = the model's dtype.  The SHORT (and the unscaled) frequencies live in the module's ``inv_freq`` /
+    ``original_inv_freq`` BUFFERS, which ``model.to(torch.bfloat16)`` - the reference driver's set-up order,
+    eval_genai_mjvideo.py:112-116 - casts like every floating buffer: they reach the forward rounded to bf16 (the same fate as
+    InternLM2's cos / sin caches).  The LONG frequencies are recomputed in fp32 inside every forward that
+    needs them (longrope_frequency_update) and are never rounded."""
     dim = int((l.hidden_size // l.num_attention_heads) * getattr(l, "partial_rotary_factor", 1.0))
     shape = torch.arange(0, dim, 2, dtype=torch.int64).float() / dim
     rs = rope_scaling_of(l)
     if rs is None:
-        return 1.0 / (float(l.rope_theta) ** shape)
-    ext = torch.tensor(rs["long_factor"] if seq_len > l.original_max_position_embeddings else rs["short_factor"], dtype=torch.float32)
-    return 1.0 / (ext * float(l.rope_theta) ** shape)
+        return (1.0 / (float(l.rope_theta) ** shape)).to(dtype).float()
+    if seq_len > l.original_max_position_embeddings:
+        return 1.0 / (torch.tensor(rs["long_factor"], dtype=torch.float32) * float(l.rope_theta) ** shape)
+    return (1.0 / (torch.tensor(rs["short_factor"], dtype=torch.float32) * float(l.rope_theta) ** shape)).to(dtype).float()
 
 
 def rope_tables(cfg, seq_len: int, dtype):
     """modeling_phi3.py:Phi3RotaryEmbedding.forward for position_ids = arange(seq_len) (the reference passes none,
     modeling_internvl_chat.py:190-199): fp32 outer product, cat(freqs, freqs), cos / sin times the attention factor, cast."""
     l = cfg.llm_config
-    f = inv_freq(l, seq_len)
+    f = inv_freq(l, seq_len, dtype)
     pos = torch.arange(seq_len, dtype=torch.float32)
     freqs = (f[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]
     emb = torch.cat((freqs, freqs), dim=-1)

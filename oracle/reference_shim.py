@@ -147,3 +147,60 @@ def build_reference_heads(config_dict: dict, head_kwargs: dict, head_state_dict:
 
     model.replay = replay
     return model
+
+
+def build_reference_model_phi3(config_dict: dict, head_kwargs: dict, state_dict: dict, dtype, img_context_token_id: int,
+                               pad_token_id, gating_pattern):
+    """BASELINE configs[4]'s backbone as the REFERENCE would run it: the reference's own ``InternVLChatRewardModeling`` /
+    ``InternVLChatModel`` code (vision tower, projector, splice, heads) around transformers' own ``Phi3ForCausalLM`` handed in
+    through the ``language_model`` argument (modeling_internvl_chat.py:100,121-122) - the wiring of the upstream InternVL2-4B
+    checkpoint, whose Phi-3 branch the reference's dispatch (:125-130) and config class (configuration_internvl_chat.py:50-55)
+    lack.  Three shims, all oracle-side: (1) the reference's config class only admits Llama / InternLM2 ``llm_config``s, and
+    reads nothing of it but ``hidden_size``: it gets a Llama-typed stand-in of the same hidden size; (2) ``Phi3ForCausalLM`` is
+    built from transformers' ``Phi3Config`` with ``attn_implementation='eager'`` (what modeling_internvl_chat.py:114 sets
+    without flash-attn); (3) ``moe_reward.token_pattern`` (the InternLM2 tokenizer's ids, moe_reward.py:45-48) is replaced by
+    ``gating_pattern`` while this model runs - restore with ``model.restore_token_pattern()``."""
+    import torch
+    import transformers
+    from transformers import Phi3Config, Phi3ForCausalLM
+    mr = load_reference()
+    from internvl2 import InternVLChatModel, InternVLChatConfig
+
+    cd = copy.deepcopy(config_dict)
+    lc = cd["llm_config"]
+    assert lc["architectures"][0] == "Phi3ForCausalLM"
+    stand_in = dict(architectures=["LlamaForCausalLM"], hidden_size=lc["hidden_size"], intermediate_size=lc["intermediate_size"],
+                    num_hidden_layers=1, num_attention_heads=lc["num_attention_heads"], vocab_size=lc["vocab_size"])
+    cd_ref = dict(cd, llm_config=stand_in)
+    cd_ref.pop("gating_token_pattern", None)
+    hf_kwargs = {k: v for k, v in lc.items() if k not in ("architectures", "attn_implementation")}
+    phi_cfg = Phi3Config(**copy.deepcopy(hf_kwargs))
+    phi_cfg._attn_implementation = "eager"
+
+    def _from_pretrained(name, *a, **k):
+        c = InternVLChatConfig(**copy.deepcopy(cd_ref))
+        lm = Phi3ForCausalLM(phi_cfg)
+        return InternVLChatModel(c, language_model=lm)
+
+    cfg = mr.InternVLChatRewardModelingConfig(**copy.deepcopy(cd_ref), **copy.deepcopy(head_kwargs))
+    orig = InternVLChatModel.from_pretrained
+    InternVLChatModel.from_pretrained = staticmethod(_from_pretrained)
+    try:
+        model = mr.InternVLChatRewardModeling("synthetic-phi3", cfg)
+    finally:
+        InternVLChatModel.from_pretrained = orig
+    model.load_state_dict(state_dict, strict=True)
+    model.config.pad_token_id = pad_token_id
+    model = model.to(dtype)
+    model.model.img_context_token_id = img_context_token_id
+    model.eval()
+    assert model.model.language_model.config._attn_implementation == "eager"
+    old = list(mr.token_pattern)
+    mr.token_pattern[:] = list(gating_pattern)
+
+    def restore():
+        mr.token_pattern[:] = old
+
+    model.restore_token_pattern = restore
+    model.transformers_version = transformers.__version__
+    return model
