@@ -48,6 +48,45 @@ HBM_PEAK_GBS = 8000.0
 ALGO_TFLOP_PER_PAIR = 25.8       # 12.9 TFLOP per video at C2 (causal-halved, LM head skipped)
 
 
+def algorithmic_tflop_per_video(cfg, n_tiles, n_tokens, image_size):
+    """SURVEY.md §8(d) / Appendix A as a function of the config: every contraction of the scoring path for ONE video (causal
+    attention halved, LM head skipped).  MJ-VIDEO-2B, 8 tiles @448^2, N = 2181: 12.9 TFLOP (the survey's figure, which the
+    headline keeps quoting as ALGO_TFLOP_PER_PAIR); used for the configs the survey gives no figure for (the 4B backbone)."""
+    v, l = cfg.vision_config, cfg.llm_config
+    d, ff, P = v.hidden_size, v.intermediate_size, v.patch_size
+    G = image_size // P
+    T = G * G + 1
+    vit = n_tiles * (2.0 * G * G * 3 * P * P * d + v.num_hidden_layers * (2.0 * T * (4 * d * d + 2 * d * ff) + 4.0 * T * T * d))
+    h = l.hidden_size
+    ntok = n_tiles * (G // 2) ** 2
+    proj = 2.0 * ntok * (4 * d * h + h * h)
+    hd = h // l.num_attention_heads
+    qkv_out = (l.num_attention_heads + 2 * l.num_key_value_heads) * hd
+    per_tok = 2.0 * (h * qkv_out + l.num_attention_heads * hd * h + 3 * h * l.intermediate_size)
+    llm = l.num_hidden_layers * (per_tok * n_tokens + 2.0 * l.num_attention_heads * hd * float(n_tokens) ** 2)
+    return (vit + proj + llm) / 1e12
+
+
+def executed_tflop_per_video(cfg, n_tokens, prefix_tokens, trim_queries):
+    """What the language tower of a forward really EXECUTES per video, relative to the algorithmic figure:
+    returns the TFLOP left out.  Always left out (since round 1, sanctioned by SURVEY.md §7.5): wo / FFN of the last decoder layer
+    on every row but the two the heads read.  ``prefix_tokens`` P > 0 (model.prefix_cache): P rows leave every Linear of every
+    layer.  ``trim_queries`` (model.trim_last_layer): the last layer projects k | v only (half of wqkv) and runs no attention
+    beyond a handful of queries."""
+    l = cfg.llm_config
+    h, ff = l.hidden_size, l.intermediate_size
+    hd = h // l.num_attention_heads
+    qkv_out = (l.num_attention_heads + 2 * l.num_key_value_heads) * hd
+    kv_out = 2 * l.num_key_value_heads * hd
+    per_tok = 2.0 * (h * qkv_out + l.num_attention_heads * hd * h + 3 * h * ff)
+    attn_layer = 2.0 * l.num_attention_heads * hd * float(n_tokens) ** 2
+    full = l.num_hidden_layers * (per_tok * n_tokens + attn_layer)
+    rows = n_tokens - prefix_tokens
+    done = (l.num_hidden_layers - 1) * (per_tok * rows + attn_layer)
+    done += 2.0 * h * (kv_out if trim_queries else qkv_out) * rows + (0.0 if trim_queries else attn_layer)
+    return (full - done) / 1e12
+
+
 def random_init_on_device(model, config, device, seed):
     """Random-init weights of the architecture, generated directly in HBM (same distributions as synth)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -175,8 +214,8 @@ def secondary_legs(model, cfg, dev, px, ids, mask):
             sec[name] = {"value": None, "error": repr(e)}
         sec[name]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
 
-    def fp8_ffn():
-        model.set_ffn_format("mxfp8")
+    def fp8_ffn(fmt="mxfp8"):
+        model.set_ffn_format(fmt)
         try:
             r, res = time_forwards(model, px, ids, mask, pairs=4, steps=10, warmup=3, profile=True)
         finally:
@@ -185,15 +224,24 @@ def secondary_legs(model, cfg, dev, px, ids, mask):
         name, k = max(f8.items(), key=lambda kv: kv[1]["ms"])
         tfl = k["flops"] / (k["ms"] * 1e-3) / 1e12
         ceiling = 1.0 / (FFN_TFLOP_PER_PAIR / MFMA_FP8_PEAK_TFLOPS + (ALGO_TFLOP_PER_PAIR - FFN_TFLOP_PER_PAIR) / MFMA_BF16_PEAK_TFLOPS)
+        covered = sorted(model_fp8_linears(fmt))
+        ffn_tf = 2 * sum({"fc1": 1650.9, "fc2": 1650.9, "w13": 3512.7, "w2": 1756.4}[n] for n in covered) / 1e3
+        ceiling = 1.0 / (ffn_tf / MFMA_FP8_PEAK_TFLOPS + (ALGO_TFLOP_PER_PAIR - ffn_tf) / MFMA_BF16_PEAK_TFLOPS)
         r.update({
-            "baseline_config": "configs[4]'s fp8 MFMA weight path on the 2B stand-in (no 4B reference exists); same batch as the headline",
-            "dtype": "fp8-e4m3 (MXFP8, block-32 e8m0 scales) operands + fp32 accumulate in the five FFN GEMMs of both towers, bf16 elsewhere",
+            "baseline_config": "configs[4]'s fp8 MFMA weight path on the 2B model (secondary.c5_4b runs it on the 4B backbone); same batch as the headline",
+            "preset": fmt, "fp8_linears": covered,
+            "rank_agreement_vs_reference_bf16": ({"spearman_224": 0.99863, "spearman_448": 0.99820, "decisive_flips": "0 / 478, 0 / 240",
+                                                  "tolerance": "its own, looser than north_star's 0.999 (tests/test_fp8_gpu.py)"} if fmt == "mxfp8" else
+                                                 {"spearman_224": 0.99920, "spearman_448": 0.99912, "decisive_flips": "0 / 478, 0 / 240",
+                                                  "tolerance": "north_star's: rho >= 0.999 and 0 flips (tests/test_fp8_gpu.py)"}),
+            "rank_agreement_source": "profiles/r06_a_fp8_ffn_subset_study.txt (engineered rank sets, all 15 subsets of the four Linears)",
+            "dtype": f"fp8-e4m3 (MXFP8, block-32 e8m0 scales) operands + fp32 accumulate in the FFN GEMMs {covered}, bf16 elsewhere",
             "roofline": {"kernel": name, "bound": "mfma", "achieved": round(tfl, 2), "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tfl / MFMA_FP8_PEAK_TFLOPS, 4), "launches": k["launches"],
                          "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4)},
             "mixed_roofline": {"ceiling_pairs_per_s": round(ceiling, 2), "frac": round(r["value"] / ceiling, 4),
-                               "note": f"{FFN_TFLOP_PER_PAIR:.2f} TFLOP of FFN per pair at the 5 PFLOP/s fp8 peak + "
-                                       f"{ALGO_TFLOP_PER_PAIR - FFN_TFLOP_PER_PAIR:.2f} TFLOP at the 2.5 PFLOP/s bf16 peak"},
+                               "note": f"{ffn_tf:.2f} TFLOP of fp8 Linears per pair at the 5 PFLOP/s fp8 peak + "
+                                       f"{ALGO_TFLOP_PER_PAIR - ffn_tf:.2f} TFLOP at the 2.5 PFLOP/s bf16 peak"},
             "fp8_kernels": {n: {"ms_per_step": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                             for n, v in sorted(f8.items(), key=lambda kv: -kv[1]["ms"])}})
         return r
@@ -228,13 +276,61 @@ def secondary_legs(model, cfg, dev, px, ids, mask):
                   "dtype": "bf16", "frac_of_mfma_roofline": round(r["value"] * ALGO_TFLOP_PER_PAIR / MFMA_BF16_PEAK_TFLOPS, 4)})
         return r
 
+    def c5_4b():
+        """BASELINE configs[4]: the InternVL2-4B backbone (InternViT + Phi-3-mini: hidden 3072, 32 heads x 96, ff 8192, 32 layers) +
+        the 28-criteria MoE heads, random-init weights, the headline's batch shape; bf16, then the fp8 weight path (both presets)."""
+        cfg4 = C.InternVLChatRewardModelingConfig(**C.internvl2_4b_config_dict(448), **C.mjvideo_head_kwargs())
+        m4 = InternVLChatRewardModeling.from_config(cfg4, dtype=torch.bfloat16, device=dev)
+        random_init_on_device(m4, cfg4, dev, seed=4321)
+        tk = synth.PHI3_TOKENS
+        m4.config.pad_token_id = tk.pad
+        m4.model.img_context_token_id = tk.img_context
+        m4.eval()
+        per_tile = num_image_tokens_per_tile(cfg4)
+        rows = []
+        for p_ in range(4):
+            row = synth.synth_input_ids(per_tile * 8, caption_seed=5000 + p_, tokens=tk)
+            rows += [row, row]
+        ids4, mask4 = synth.pad_batch(rows, pad_id=tk.pad)
+        ids4, mask4 = ids4.to(dev), mask4.to(dev)
+        n4 = int(ids4.shape[1])
+        algo = 2 * algorithmic_tflop_per_video(cfg4, 8, n4, 448)
+        out = {"baseline_config": "configs[4]: InternVL2-4B backbone (InternViT-300M + Phi-3-mini) + 28-criteria MoE heads, 4 pairs of 8 frames "
+                                  "@448^2 on ONE MI355X (the 8-GPU form is this shard under score_pairs_dp)",
+               "N": n4, "parameters_G": round(sum(p_.numel() for p_ in m4.parameters()) / 1e9, 3),
+               "algorithmic_tflop_per_pair": round(algo, 2), "roofline_pairs_per_s_bf16": round(MFMA_BF16_PEAK_TFLOPS / algo, 2),
+               "oracle": "oracle/ref_phi3.py, pinned to transformers 5.15's Phi3ForCausalLM inside the reference's reward model "
+                         "(tests/golden/make_golden_phi3.py); no reference implementation of a 4B MJ-VIDEO exists (README.md:18)"}
+        try:
+            for name, fmt in (("bf16", "bf16"), ("fp8_ffn", "mxfp8"), ("fp8_rank999", "mxfp8-rank999")):
+                m4.set_ffn_format(fmt)
+                r, res = time_forwards(m4, px, ids4, mask4, pairs=4, steps=5, warmup=2, profile=True)
+                r["frac_of_bf16_mfma_roofline"] = round(r["value"] * algo / MFMA_BF16_PEAK_TFLOPS, 4)
+                top = sorted(res.items(), key=lambda kv: -kv[1]["ms"])[:8]
+                r["kernels"] = {k: {"ms_per_step": round(v["ms"], 3),
+                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None}
+                                for k, v in top}
+                out[name] = r
+            out["value"] = out["bf16"]["value"]
+        finally:
+            del m4
+            torch.cuda.empty_cache()
+        return out
+
     if model.prefix_cache or model.trim_last_layer:
         leg("prefix_cache_off", prefix_cache_off)
     leg("fp8_ffn", fp8_ffn)
+    leg("fp8_rank999", lambda: fp8_ffn("mxfp8-rank999"))
     leg("pairs8", pairs8)
     leg("c4_112_tiles", c4)
+    leg("c5_4b", c5_4b)
     torch.cuda.empty_cache()
     return sec
+
+
+def model_fp8_linears(fmt):
+    from mj_video_amd.modeling import FFN_LINEARS, FP8_PRESETS
+    return FP8_PRESETS.get(fmt, FFN_LINEARS)
 
 
 def dp_step(score_local, global_pairs, device):
@@ -453,9 +549,23 @@ def main():
                        "prefix_cache": bool(model.prefix_cache), "prefix_cache_tokens": (model._prefix or {}).get("P", 0),
                        "prefix_cache_hits": model.prefix_cache_hits, "trim_last_layer": bool(model.trim_last_layer),
                        "parallelism": f"dp{world} (replicated weights, one all-gather of [pairs,2,34] fp32 per step)"},
-            "frac_of_mfma_roofline": round(value * ALGO_TFLOP_PER_PAIR / (MFMA_BF16_PEAK_TFLOPS * world), 4)
-            if (S, F) == (448, 8) and not args.fp8 else None,
         }
+        if (S, F) == (448, 8) and not args.fp8:
+            # the roofline fraction is quoted on EXECUTED flops (VERDICT r5 item 9 / ADVICE r5): the algorithmic 25.8 TFLOP per
+            # pair minus what this run's switches leave out of the language tower
+            left_out = 2 * executed_tflop_per_video(cfg, seq_len, (model._prefix or {}).get("P", 0) if model.prefix_cache else 0,
+                                                    bool(model.trim_last_layer))
+            line["executed_tflop_per_pair"] = round(ALGO_TFLOP_PER_PAIR - left_out, 3)
+            line["frac_of_mfma_roofline"] = round(value * (ALGO_TFLOP_PER_PAIR - left_out) / (MFMA_BF16_PEAK_TFLOPS * world), 4)
+            line["frac_of_mfma_roofline_note"] = (
+                f"value x executed TFLOP per pair / 2.5 PFLOP/s: {ALGO_TFLOP_PER_PAIR} algorithmic (SURVEY.md §8(d)) minus {left_out:.3f} "
+                "this run leaves out of the language tower (cached prompt-prefix rows in every layer; last decoder layer: q projection + "
+                "attention beyond the rows the heads read, wo / FFN on every other row).  `value_all_work` = the same batch with "
+                "prefix_cache / trim_last_layer off (every row in every forward), `frac_all_work` its fraction on ITS executed flops")
+            line["pairs_per_s_roofline"] = round(MFMA_BF16_PEAK_TFLOPS * world / ALGO_TFLOP_PER_PAIR, 2)
+            line["value_all_work"] = None
+        else:
+            line["frac_of_mfma_roofline"] = None
         from mj_video_amd import _lib
         lib_path = os.environ.get("MJV_LIBRARY") or _lib.LIB_PATH
         line["library"] = {"path": os.path.relpath(lib_path, ROOT), "bench_build": hasattr(_lib.load_library(), "mjv_bench_gemm_set")
@@ -519,6 +629,12 @@ def main():
         if (world == 1 and not use_dist and not args.no_secondary and not args.fp8 and (S, F, args.pairs) == (448, 8, 4)
                 and not os.environ.get("MJV_BENCH_NORM_FUSION") and not args.gemm_code):
             line["secondary"] = secondary_legs(model, cfg, dev, px, ids, mask)
+            off = line["secondary"].get("prefix_cache_off")
+            if off and off.get("value"):
+                lo = 2 * executed_tflop_per_video(cfg, seq_len, 0, False)
+                line["value_all_work"] = off["value"]
+                line["frac_all_work"] = round(off["value"] * (ALGO_TFLOP_PER_PAIR - lo) / MFMA_BF16_PEAK_TFLOPS, 4)
+                off["frac_of_mfma_roofline"] = line["frac_all_work"]
         if world == 1 and not args.no_cpu_baseline and not args.fp8:
             # oneDNN bf16 GEMMs stop scaling (and oversubscribe NUMA domains) far below a 256-thread host: cap at 32
             cpu_model, phys, logical = host_cpu_info()

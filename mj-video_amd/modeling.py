@@ -489,9 +489,11 @@ class InternVLChatRewardModeling(nn.Module):
         # prefix_cache: every prompt starts with the same tokens (system prompt + "Frame1: <img>": conversation.py:354-365,
         #   eval_genai_mjvideo.py:132-137); under the causal mask their hidden states - and so their keys / values in all 24
         #   layers - depend on the weights and those ids alone.  The first forward that meets a prefix runs the tower over its
-        #   first 64 * k tokens ALONE (_build_prefix) and keeps every layer's K / V rows; every forward - that first one included,
-        #   so a result never depends on whether the cache was warm - leaves those rows out of every GEMM / norm of the tower
-        #   and attends to the cached keys (mjv_attn_desc.prefix_k / prefix_v).  Invalidated by any parameter change
+        #   first 64 * k tokens ALONE (_build_prefix) and keeps every layer's K / V rows; every forward - that first one included:
+        #   a cold and a warm cache run the same computation - leaves those rows out of every GEMM / norm of the tower
+        #   and attends to the cached keys (mjv_attn_desc.prefix_k / prefix_v).  Cached vs uncached evaluation: equal up to fp32
+        #   re-association (bit-identical when no GEMM slices K); which of the two a forward gets depends on the batch's
+        #   common prefix and on the thrash guard's history (_forward_group) - prefix_cache = False is the history-free mode.  Invalidated by any parameter change
         #   (load_state_dict, .to()), another prefix, another rotary base (dynamic NTK), another numerics setting.  False =
         #   recompute them every forward, as the reference does.
         self.prefix_cache = True
@@ -661,15 +663,8 @@ class InternVLChatRewardModeling(nn.Module):
         ``seq_len`` is the padded width of ``input_ids`` (``kv_seq_len`` of :367-372), as the reference passes it."""
         lc = self.config.llm_config
         dim = lc.hidden_size // lc.num_attention_heads
-        maxpos = lc.max_position_embeddings
         rs = lc.rope_scaling
-        st = self._rope_state
-        if st is None:
-            st = self._rope_state = dict(cached=maxpos, base=float(lc.rope_theta))
-        if seq_len > st["cached"]:
-            st["cached"] = seq_len
-            if rs is not None and rs["type"] == "dynamic" and seq_len > maxpos:
-                st["base"] = float(lc.rope_theta) * ((rs["factor"] * seq_len / maxpos) - (rs["factor"] - 1)) ** (dim / (dim - 2))
+        st = self._rope_state = self._rope_next_state(seq_len)
         n = max(st["cached"], 1)
         key = (n, st["base"], str(device))
         if key in self._rope:
@@ -683,6 +678,22 @@ class InternVLChatRewardModeling(nn.Module):
         tabs = (emb.cos().to(BF16).to(device).contiguous(), emb.sin().to(BF16).to(device).contiguous())
         self._rope = {key: tabs}
         return tabs
+
+    def _rope_next_state(self, seq_len: int) -> dict:
+        """the rotary cache state (cached length, base) a forward of padded width ``seq_len`` leaves behind - computed WITHOUT
+        touching ``self._rope_state``: ``_forward_group`` needs the base for its prefix-cache key before the batch is validated,
+        and a forward that is then rejected (bad ids, <IMG_CONTEXT> count mismatch ...) must not advance the state - the
+        reference's rotary modules only see sequences that reach the language tower."""
+        lc = self.config.llm_config
+        dim = lc.hidden_size // lc.num_attention_heads
+        maxpos = lc.max_position_embeddings
+        rs = lc.rope_scaling
+        st = dict(self._rope_state) if self._rope_state is not None else dict(cached=maxpos, base=float(lc.rope_theta))
+        if seq_len > st["cached"]:
+            st["cached"] = seq_len
+            if rs is not None and rs["type"] == "dynamic" and seq_len > maxpos:
+                st["base"] = float(lc.rope_theta) * ((rs["factor"] * seq_len / maxpos) - (rs["factor"] - 1)) ** (dim / (dim - 2))
+        return st
 
     def _rope_tables_phi3(self, seq_len: int, device):
         """bf16 cos / sin tables [seq_len rounded up to 1024, rotary_dim] of transformers/models/phi3/modeling_phi3.py:
@@ -1247,8 +1258,8 @@ class InternVLChatRewardModeling(nn.Module):
         if self._phi3:
             settings = None
         else:
-            self._rope_tables(int(input_ids.shape[1]), dev)   # (advances the rotary state exactly as the tower will see it)
-            settings = (self._derived_sig, self._rope_state["base"], self.attention_scores, self.ffn_format, bool(self.norm_fusion),
+            # (the rotary base this forward WILL rotate with - the state itself advances in the tower, after the batch is validated)
+            settings = (self._derived_sig, self._rope_next_state(int(input_ids.shape[1]))["base"], self.attention_scores, self.ffn_format, bool(self.norm_fusion),
                         self._exp8_set(), bool(self.use_gemm_workspace), tail_form, str(dev))
         use_prefix = bool(self.prefix_cache and trimmed and not self._phi3)
         hit = []
@@ -1261,17 +1272,23 @@ class InternVLChatRewardModeling(nn.Module):
                 self._prefix_misses = 0
                 return True
             # a prefix this model holds no keys / values for (first forward, new weights, another prompt, another setting):
-            # computed once, by a pass over the prefix tokens ALONE, before this forward's tower - so that a forward's result
-            # never depends on whether the cache was warm (the same cached computation either way).  A caller whose prompts
-            # share NO constant prefix (every forward another one) would pay that pass - about 3 ms - for nothing each time:
-            # after three misses in a row the prefix is only rebuilt when a candidate REPEATS, and forwards in between run
-            # uncached (every row, as prefix_cache = False does).
+            # computed once, by a pass over the prefix tokens ALONE, before this forward's tower - a cold and a warm cache run
+            # the same cached computation.  A caller whose prompts share NO constant prefix (every forward another one) would
+            # pay that pass - about 3 ms - for nothing each time: after three misses in a row the prefix is only rebuilt when a
+            # candidate REPEATS, and forwards in between run uncached (every row, as prefix_cache = False does).
+            # What that makes a result depend on: the cached and the uncached evaluation of one batch are the same
+            # function up to the re-association of fp32 sums - bit-identical when no GEMM slices K, a few per cent of the hidden
+            # rows' norm otherwise (tests/test_e2e_gpu.py::test_prefix_cache_is_invisible_and_invalidates) - and WHICH of the two
+            # runs depends on the call history (this guard) and on the batch (the prefix is what all its samples share).  A
+            # caller that needs history-independent bits sets prefix_cache = False (scripts/eval: --no-prefix-cache).
             key = (settings, prefix_ids.tobytes())
             self._prefix_misses += 1
             repeat = self._prefix_last_miss == key
             self._prefix_last_miss = key
             if self._prefix_misses > 3 and not repeat:
                 return False
+            if repeat:
+                self._prefix_misses = 0      # a stable prefix again: the next change of prompt gets its three tries back
             self._build_prefix(d, prefix_ids, settings, int(input_ids.shape[1]), dev)
             return True
 

@@ -74,11 +74,15 @@ def inv_freq(l, seq_len: int, dtype=torch.float32) -> torch.Tensor:
     return (1.0 / (torch.tensor(rs["short_factor"], dtype=torch.float32) * float(l.rope_theta) ** shape)).to(dtype).float()
 
 
-def rope_tables(cfg, seq_len: int, dtype):
+def rope_tables(cfg, seq_len: int, dtype, buffer_dtype=None):
     """modeling_phi3.py:Phi3RotaryEmbedding.forward for position_ids = arange(seq_len) (the reference passes none,
-    modeling_internvl_chat.py:190-199): fp32 outer product, cat(freqs, freqs), cos / sin times the attention factor, cast."""
+    modeling_internvl_chat.py:190-199): fp32 outer product, cat(freqs, freqs), cos / sin times the attention factor, cast.
+    ``buffer_dtype``: the dtype the rotary module's buffers were cast to (default: ``dtype``, i.e. ``model.to(dtype)``).  The
+    fp32 runs that measure the bf16 run's NOISE pass bfloat16 here: with fp32 buffers the short-factor frequencies differ from
+    the bf16 model's by up to 2^-9 relative - radians of phase at positions in the thousands, a different positional encoding,
+    not rounding noise (one decoder layer at 4B dims: 6.8 % against 0.56 % with the same frequencies)."""
     l = cfg.llm_config
-    f = inv_freq(l, seq_len, dtype)
+    f = inv_freq(l, seq_len, dtype if buffer_dtype is None else buffer_dtype)
     pos = torch.arange(seq_len, dtype=torch.float32)
     freqs = (f[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]
     emb = torch.cat((freqs, freqs), dim=-1)
@@ -154,8 +158,10 @@ def find_token_for_gating(lst: Sequence[int], pattern: Sequence[int]) -> int:
 @torch.no_grad()
 def reward_forward(sd: Dict[str, torch.Tensor], cfg, pixel_values: torch.Tensor, input_ids: torch.Tensor,
                    attention_mask: Optional[torch.Tensor], img_context_token_id: int, pad_token_id: Optional[int],
-                   gating_pattern: Sequence[int], lm_head: bool = False, probes: Optional[dict] = None) -> Dict[str, torch.Tensor]:
-    """moe_reward.py:183-297 on modeling_internvl_chat.py:146-226 with a Phi-3 language model (see the module docstring)."""
+                   gating_pattern: Sequence[int], lm_head: bool = False, probes: Optional[dict] = None,
+                   rope_buffer_dtype=None) -> Dict[str, torch.Tensor]:
+    """moe_reward.py:183-297 on modeling_internvl_chat.py:146-226 with a Phi-3 language model (see the module docstring).
+    ``rope_buffer_dtype``: see ``rope_tables`` (fp32 noise-floor runs of a bf16 model pass torch.bfloat16)."""
     l = cfg.llm_config
     x = F.embedding(input_ids, sd["model.language_model.model.embed_tokens.weight"]).clone()
     vit = ref_cpu.extract_feature(sd, cfg, pixel_values, probes)
@@ -171,7 +177,7 @@ def reward_forward(sd: Dict[str, torch.Tensor], cfg, pixel_values: torch.Tensor,
     if attention_mask is None:
         attention_mask = torch.ones((B, N), dtype=torch.bool)
     mask = causal_padding_mask(attention_mask, x.dtype)
-    cos, sin = rope_tables(cfg, N, x.dtype)
+    cos, sin = rope_tables(cfg, N, x.dtype, rope_buffer_dtype)
     for i in range(l.num_hidden_layers):
         x = layer(sd, cfg, i, x, mask, cos, sin)
         if probes is not None:

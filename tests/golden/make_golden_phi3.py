@@ -49,7 +49,10 @@ def make_cfg(kind: str, image_size: int, **llm_over):
 
 
 def oracle(sd, cfg, px, ids, mask, probes=None):
-    return ref_phi3.reward_forward(sd, cfg, px, ids, mask, TK.img_context, TK.pad, cfg.gating_token_pattern, probes=probes)
+    """(the fp32 runs keep the bf16 model's rotary frequencies - ref_phi3.rope_tables ``buffer_dtype`` - so that they measure
+    the bf16 run's rounding noise, not another positional encoding)"""
+    return ref_phi3.reward_forward(sd, cfg, px, ids, mask, TK.img_context, TK.pad, cfg.gating_token_pattern, probes=probes,
+                                   rope_buffer_dtype=torch.bfloat16)
 
 
 def gen_tiny():
@@ -136,7 +139,9 @@ def gen_layers(wseed=0, xseed=43):
             layer = Phi3DecoderLayer(pc, 0)
             layer.load_state_dict({k: v.to(dt) for k, v in w.items()}, strict=True)
             layer = layer.to(dt).eval()
-            rot = Phi3RotaryEmbedding(pc).to(dt)   # (model.to(dtype) casts the rotary module's inv_freq buffers too: ref_phi3.inv_freq)
+            # model.to(bfloat16) casts the rotary module's inv_freq buffers too (ref_phi3.inv_freq); the fp32 run keeps those
+            # bf16-rounded frequencies: it measures the bf16 run's rounding noise, not another positional encoding
+            rot = Phi3RotaryEmbedding(pc).to(torch.bfloat16)
             xd = x.to(dt)
             pos = torch.arange(N).unsqueeze(0)
             mask = create_causal_mask(config=pc, inputs_embeds=xd, attention_mask=torch.ones(1, N, dtype=torch.long),

@@ -179,3 +179,76 @@ def test_exception_in_score_fn_reaches_every_rank_after_the_collective():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results[1] == "RuntimeError: boom on rank 1" and results[0] == "ValueError names rank 1", results
+
+
+def _world8_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = {}
+    for n_pairs in (64, 61, 3):
+        pairs = list(range(500, 500 + n_pairs))
+        calls = []
+
+        def score_fn(local):
+            calls.append(list(local))
+            return fake_scores(local)
+
+        out = parallel.score_pairs_dp(score_fn, pairs, device=torch.device("cpu"))
+        rec[n_pairs] = (out, calls)
+    # error path at world 8: rank 5's model throws on a 61-pair batch; the others must come back with a ValueError naming it
+    def bad(local):
+        if rank == 5:
+            raise RuntimeError("boom on rank 5")
+        return fake_scores(local)
+    try:
+        parallel.score_pairs_dp(bad, list(range(61)), device=torch.device("cpu"))
+        rec["error"] = "ok"
+    except RuntimeError as e:
+        rec["error"] = f"RuntimeError: {e}"
+    except ValueError as e:
+        rec["error"] = "ValueError" + (" names rank 5" if "[5]" in str(e) else str(e))
+    # ... and the group still works afterwards (nobody is left inside a collective)
+    rec["after"] = parallel.score_pairs_dp(fake_scores, list(range(16)), device=torch.device("cpu"))
+    q.put((rank, rec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world8_dry_run():
+    """The first hardware SCALE run is 8 ranks (BASELINE configs[2]: 64 pairs over 8 MI355X) and has never executed on GPUs:
+    this is its sharding arithmetic at world size 8 over gloo - 64 pairs (8 per rank, bench.py's shard), 61 (uneven: five ranks
+    take 8, three take 7) and 3 (five ranks with EMPTY shards): every rank ends with the whole block in pair order bit for bit,
+    every pair is scored exactly once and by the rank that owns its contiguous block, a throwing rank reaches everyone after the
+    collective, and the group keeps working."""
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for n_pairs in (64, 61, 3):
+        pairs = list(range(500, 500 + n_pairs))
+        single = fake_scores(pairs)
+        seen = []
+        for rank in range(world):
+            out, calls = results[rank][n_pairs]
+            assert torch.equal(out, single), (n_pairs, rank)
+            lo, hi = parallel.shard_bounds(n_pairs, world, rank)
+            assert calls == ([pairs[lo:hi]] if hi > lo else []), (n_pairs, rank, calls)
+            seen += [x for c in calls for x in c]
+        assert seen == pairs                                   # rank order == pair order, each pair exactly once
+    sizes = [parallel.shard_bounds(61, world, r) for r in range(world)]
+    assert [b - a for a, b in sizes] == [8, 8, 8, 8, 8, 7, 7, 7] and sizes[0][0] == 0 and sizes[-1][1] == 61
+    assert [b - a for a, b in (parallel.shard_bounds(3, world, r) for r in range(world))] == [1, 1, 1, 0, 0, 0, 0, 0]
+    for rank in range(world):
+        assert results[rank]["error"] == ("RuntimeError: boom on rank 5" if rank == 5 else "ValueError names rank 5"), results[rank]["error"]
+        assert torch.equal(results[rank]["after"], fake_scores(list(range(16))))

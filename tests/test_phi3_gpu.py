@@ -255,7 +255,7 @@ def test_phi3_single_layer_at_4b_dims(cuda, name, scores):
 @pytest.mark.parametrize("size", [224])
 def test_phi3_full_4b_dims_against_golden(cuda, size):
     """tests/golden/phi3_full_<size>.npz: InternVL2-4B dims end to end (4.1 G parameters), 8 frames per video, all videos of the
-    fixture in one forward: layer probes within the random-walk model of test_e2e_gpu.layer_tol, hidden rows within 1.5 x the
+    fixture in one forward: layer probes within 2 x the reference's own bf16-vs-fp32 distance at that layer, hidden rows within 1.5 x the
     reference's own bf16-vs-fp32 distance, head outputs within 3 x its noise floor, rms over the videos within 2 x its rms."""
     from mj_video_amd import synth
     try:
@@ -275,18 +275,21 @@ def test_phi3_full_4b_dims_against_golden(cuda, size):
     pre = [f"v{v['video_idx']}" for v in vids]
     tiles = vids[0]["n_tiles"]
     cu_rows = np.concatenate([[0], np.cumsum([int(m.sum()) for m in mask])])
-    one_vit, one_llm = 0.0030, 0.0050     # per-layer bf16 noise: the vision layers of test_e2e_gpu; phi3_layers.json for the decoder
+    # per layer: the fixture holds the same rows from the fp32 run, i.e. the reference's OWN bf16 noise at that depth (vision
+    # 0.4 % -> 1.3 %, decoder 1.0 % -> 4.5 % over its 32 layers at these dims); two samples of one noise differ by sqrt(2) x one:
+    # bound 2 x, against the bf16 run and against the fp32 run
     rep = []
-    for L in rp["vit_layers"]:
-        e = rel_l2(probes[f"vit_layer{L}"][0, :rp["vit_rows"], :].float().cpu().numpy(), bits_to_f32(npz[f"v0/probe/vit_layer{L}_rows"]))
-        rep.append((f"vit{L}", round(e, 4)))
-        assert e < min(2.0 * one_vit * np.sqrt(L + 1), 0.03), ("vit", L, e)
-    for L in rp["llm_layers"]:
-        got = probes[f"llm_layer{L}"][int(cu_rows[1]) - rp["llm_rows"]:int(cu_rows[1]), :].float().cpu().numpy()
-        e = rel_l2(got, bits_to_f32(npz[f"v0/probe/llm_layer{L}_rows"]))
-        rep.append((f"llm{L}", round(e, 4)))
-        assert e < min(2.0 * float(np.sqrt(one_llm ** 2 * (L + 1) + 0.0048 ** 2)), 0.045), ("llm", L, e)
-    print("layer probes (relative L2 vs the reference):", rep)
+    for tower, layers in (("vit", rp["vit_layers"]), ("llm", rp["llm_layers"])):
+        for L in layers:
+            if tower == "vit":
+                got = probes[f"vit_layer{L}"][0, :rp["vit_rows"], :].float().cpu().numpy()
+            else:
+                got = probes[f"llm_layer{L}"][int(cu_rows[1]) - rp["llm_rows"]:int(cu_rows[1]), :].float().cpu().numpy()
+            ref, f32 = bits_to_f32(npz[f"v0/probe/{tower}_layer{L}_rows"]), npz[f"v0/probe/fp32/{tower}_layer{L}_rows"]
+            noise, e, e32 = rel_l2(ref, f32), rel_l2(got, ref), rel_l2(got, f32)
+            rep.append((f"{tower}{L}", round(e, 4), round(e32, 4), round(noise, 4)))
+            assert e <= 2.0 * noise and e32 <= 2.0 * noise, (tower, L, e, e32, noise)
+    print("layer probes (layer, HIP vs reference bf16, HIP vs its fp32 run, reference bf16 vs fp32):", rep)
     devs = {"score": [], "aspect_scores": [], "rewards": []}
     for i, p in enumerate(pre):
         for f in FIELDS:
