@@ -850,7 +850,7 @@ def test_attention_long_context_c4(cuda, attn_variant):
         assert (got - ref).abs().max().item() < 0.03
 
 
-@pytest.mark.parametrize("D,H,G", [(128, 4, 2), (64, 2, 1)])
+@pytest.mark.parametrize("D,H,G", [(128, 4, 2), (64, 2, 1), (96, 4, 1)])
 @pytest.mark.parametrize("P,lens,qlens", [
     (0, [2186, 700, 131], [5, 700, 64]),          # suffix queries only (the last decoder layer of a scorer)
     (64, [2122, 636, 67, 1], [2122, 636, 67, 1]),  # a shared 64-key prefix, every own row a query (the prompt-prefix cache)
