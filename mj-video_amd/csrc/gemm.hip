@@ -1512,6 +1512,195 @@ thread_local int g_num_cus = 256;   // CUs of the device of the call in flight (
 // skip work (wrong results by construction) are not compiled, and what a caller may choose - the tile kernel, for parity
 // tests - travels in the call's descriptor (mjv_gemm_desc.tile).  -DMJV_BENCH (make bench -> libmjv_hip_bench.so, loaded by
 // tools/gemm_bench.py and friends) turns them into process-wide settings behind mjv_bench_gemm_set().
+// ============================================================================================ 128 x 256, two workgroups per CU
+// Round 6: the structural alternative to "one 256 x 256 workgroup owns the CU" for the SHORT-K Linears of the
+// vision tower (qkv, fc1, proj: K = 1024 = 16 K-tiles of the 256^2 kernel, where the un-overlapped epilogue is a quarter to a
+// third of a tile's life).  A 128 (activation rows) x 256 (weight rows) tile with HALF the accumulators' footprint per
+// workgroup: 256 threads = 4 waves as 2 (M) x 2 (N), each wave a 64 x 128 sub-tile = the same 128 accumulator registers per lane,
+// K-steps of 32 (one 16x16x32 MFMA deep) so that three pipeline stages are 72 KiB and TWO workgroups share a CU: one
+// workgroup's epilogue (LDS round trip, table gathers, global stores) runs beside the other's main loop - the hardware
+// dispatches a new workgroup whenever one retires, so the two drift apart by themselves.  Price: 1.5 x the L2 -> LDS fill per flop
+// of the 256^2 tile.  LDS image per stage: A rows then W rows, 64-byte rows (32 k), 16-byte chunk c of row r at chunk
+// c ^ ((-(r >> 2)) & 3) - the 16 lanes of a ds_read_b128 group then differ in (r & 3, chunk'), conflict-free by enumeration.
+// Epilogues: bias / bias + GELU (a 6-KiB sub-range of the committed table, |x| in [2^-9, 8): below it GELU = x / 2, above it x or
+// -0 for every bf16 input - checked exhaustively) / LayerScale + residual; plain output rows only.
+namespace t2 {
+constexpr int BM = 128, BN = 256, BK = 32, NST = 3;
+constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES, PIPE = NST * STAGE;
+constexpr int EP = BN * 2 + 16;                                       // staged output row pitch (528 B: conflict-free 8-B fragment writes)
+static_assert(BM * EP <= PIPE, "the staged output tile reuses the pipeline buffers");
+constexpr int GT_LO = 0x3B00, GT_HI = 0x4100, GT_R = GT_HI - GT_LO;   // |x| bit patterns the LDS copy of the table covers
+constexpr int GT_BYTES = 2 * GT_R * 2;                                // both signs
+static_assert(GT_LO >= MJV_GELU_LO && GT_HI <= MJV_GELU_HI && (GT_R * 2) % 1024 == 0 && ((GT_LO - MJV_GELU_LO) * 2) % 16 == 0, "sub-table");
+constexpr int LDS_BYTES = PIPE + GT_BYTES;
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+MJV_DEV float gelu_sub(float xf, const u16* tab) {
+  const unsigned u = __float_as_uint(xf);
+  const unsigned mag = (u >> 16) & 0x7fffu, rel = mag - GT_LO;
+  const bool in_tab = rel < (unsigned)GT_R;
+  const unsigned t = tab[(u >> 31) * GT_R + (in_tab ? rel : 0u)];
+  const unsigned other = mag < GT_LO ? __float_as_uint(0.5f * xf) : gelu_beyond_table(u, mag);
+  return __uint_as_float(in_tab ? (t << 16) : other);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int tm, tn;
+  tile_of_block(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.K / BK;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // bias of this lane's 8 x 4 output columns, requested first (oldest entries of the in-order vmcnt queue)
+  u32x2 braw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    braw[j] = u32x2{0u, 0u};
+    const int n = n0 + wn * 128 + j * 16 + l4 * 4;
+    if (p.bias && n < p.N) braw[j] = *(const u32x2*)(p.bias + n);
+  }
+  // this wave's six 1-KiB DMA pieces of a stage: pieces w, w + 4, ... of {A rows 0-127 (8 pieces), W rows 0-255 (16)}; a piece =
+  // 16 rows x 64 B, lane -> (row = lane >> 2, LDS chunk = lane & 3), source chunk = LDS chunk ^ swizzle(row)
+  const u16* src[6];
+  int dst[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int piece = wave + 4 * q;
+    const bool is_w = piece >= 8;
+    const int r = (is_w ? piece - 8 : piece) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((-(r >> 2)) & 3);
+    int gr = (is_w ? n0 : m0) + r;
+    const int mx = (is_w ? p.N : p.M) - 1;
+    gr = gr < mx ? gr : mx;
+    src[q] = (is_w ? p.W + (long)gr * p.ldw : p.A + (long)gr * p.lda) + c * 8;
+    dst[q] = (is_w ? A_BYTES + (piece - 8) * 1024 : piece * 1024);
+  }
+  auto stage = [&](int t) __attribute__((always_inline)) {
+    char* base = smem + (t % NST) * STAGE;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + t * BK),
+                                       (__attribute__((address_space(3))) void*)(base + dst[q]), 16, 0, 0);
+  };
+  if constexpr (EPI == MJV_EPI_BIAS_GELU) {   // the table's sub-range behind the pipeline: 6 pieces of 1 KiB, older than every K-step DMA
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      if ((q & 3) == wave) {
+        const int sgn = q / 3, part = q % 3;
+        const u16* g = g_gelu_table + sgn * MJV_GELU_NEG_OFF + (GT_LO - MJV_GELU_LO) + part * 512 + lane * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(smem + PIPE + q * 1024), 16, 0, 0);
+      }
+  }
+  stage(0);
+  if (nk > 1) stage(1);
+
+  // per-lane fragment offsets inside a stage: rows of 64 B, chunk l4 ^ swizzle(row); (row >> 2) & 3 == (l15 >> 2) for every fragment
+  const int fsw = (l4 ^ ((-(l15 >> 2)) & 3)) << 4;
+  const int a_off = (wm * 64 + l15) * 64 + fsw;
+  const int w_off = A_BYTES + (wn * 128 + l15) * 64 + fsw;
+
+  for (int t = 0; t < nk; ++t) {
+    // stage t has landed (this wave's pieces: everything but the 6 of stage t + 1), every wave is past its reads of stage t - 1
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MJV_BARRIER();
+    if (t + 2 < nk) stage(t + 2);
+    const char* sb = smem + (t % NST) * STAGE;
+    bf16x8 af[4], wf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[j] = *(const bf16x8*)(sb + w_off + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sb + a_off + i * 16 * 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), in a form the compiler's wait-count pass reads (bias registers)
+  MJV_BARRIER();                        // every wave is done with the pipeline buffers: the staged tile takes their place
+
+  // ---- pass A (fragment layout: lane = output row, 4 consecutive columns): + bias, first rounding, activation -> bf16 tile in LDS
+  const u16* gtab = (const u16*)(smem + PIPE);
+  float sc4[8][4];
+  if constexpr (EPI == MJV_EPI_SCALE_RES) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = n0 + wn * 128 + j * 16 + l4 * 4;
+      u32x2 sr = {0x3f803f80u, 0x3f803f80u};
+      if (p.scale && n < p.N) sr = *(const u32x2*)(p.scale + n);
+      sc4[j][0] = __uint_as_float(sr[0] << 16); sc4[j][1] = __uint_as_float(sr[0] & 0xffff0000u);
+      sc4[j][2] = __uint_as_float(sr[1] << 16); sc4[j][3] = __uint_as_float(sr[1] & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float b4[4] = {__uint_as_float(braw[j][0] << 16), __uint_as_float(braw[j][0] & 0xffff0000u),
+                         __uint_as_float(braw[j][1] << 16), __uint_as_float(braw[j][1] & 0xffff0000u)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r] + b4[r]);
+      if constexpr (EPI == MJV_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_sub(v[r], gtab);
+      } else if constexpr (EPI == MJV_EPI_SCALE_RES) {
+        if (p.scale) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rbf(v[r] * sc4[j][r]);
+        }
+      }
+      const int ml = wm * 64 + i * 16 + l15, nl = wn * 128 + j * 16 + l4 * 4;
+      *(u32x2*)(smem + ml * EP + nl * 2) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    }
+  }
+  MJV_BARRIER();
+  // ---- pass B (row layout: 32 lanes x 16 B = one 512-B output row): residual, coalesced 16-B stores
+  const int c8 = (tid & 31) * 8, r0 = tid >> 5;     // 8 rows per pass, 16 passes
+  const int n = n0 + c8;
+  u32x4 rsv[16];
+  if constexpr (EPI == MJV_EPI_SCALE_RES) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int m = m0 + it * 8 + r0;
+      rsv[it] = u32x4{0u, 0u, 0u, 0u};
+      if (m < p.M && n < p.N) rsv[it] = *(const u32x4*)(p.res + (long)(p.m_base + m) * p.ldr + n);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int ml = it * 8 + r0, m = m0 + ml;
+    u32x4 o = *(const u32x4*)(smem + ml * EP + c8 * 2);
+    if constexpr (EPI == MJV_EPI_SCALE_RES) {
+      float a[8], b[8];
+      unpack8(o, a);
+      unpack8(rsv[it], b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += b[e];
+      o = pack8(a);
+    }
+    if (m < p.M && n < p.N) store16(p.C + (long)(p.m_base + m) * p.ldc + n, o, p.nt_store);
+  }
+}
+}  // namespace t2
+
 struct GemmTune {
   int gm = 0;               // group-M of the 256-tile order: 0 = by shape (pick_gm)
   int skinny_max_m = 128;   // problems with at most this many rows run on the 64 x 32 kernel
@@ -1653,6 +1842,23 @@ int launch(GemmArgs a, hipStream_t s, bool big, bool skinny = false) {
   return mjv_check_launch("gemm_bf16");
 }
 
+// the 128 x 256 two-per-CU kernel (tile code 2): K % 32 == 0, N % 8 == 0, plain output rows, bias / bias + GELU / LayerScale + residual
+template <int EPI>
+int launch_t2(GemmArgs a, hipStream_t s) {
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)t2::gemm2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, t2::LDS_BYTES);
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  a.tiles_m = (a.M + t2::BM - 1) / t2::BM;
+  a.tiles_n = (a.N + t2::BN - 1) / t2::BN;
+  hipLaunchKernelGGL((t2::gemm2_kernel<EPI>), dim3(a.tiles_m * a.tiles_n), dim3(256), t2::LDS_BYTES, s, a);
+  return mjv_check_launch("gemm_bf16");
+}
+
 }  // namespace
 
 // Group-M per shape class, from sweeps on the model's shapes (tools/gemm_bench.py 2003 ... 2016, best of 6 rounds, two
@@ -1689,7 +1895,7 @@ extern "C" int mjv_bench_gemm_stamp_buffer(void* p) {
 extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   MJV_REQUIRE(d && d->A && d->W && d->C, "gemm: null pointer");
   MJV_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
-  MJV_REQUIRE(d->tile == 0 || d->tile == 64 || d->tile == 128 || d->tile == 256, "gemm: tile %d not in {0, 64, 128, 256}", d->tile);
+  MJV_REQUIRE(d->tile == 0 || d->tile == 2 || d->tile == 64 || d->tile == 128 || d->tile == 256, "gemm: tile %d not in {0, 2, 64, 128, 256}", d->tile);
   if (d->a_format != MJV_FMT_BF16 || d->w_format != MJV_FMT_BF16) return mjv_gemm_mxfp8_dispatch(d, stream);   // gemm_fp8.hip
   MJV_REQUIRE(d->c_format == MJV_FMT_BF16, "gemm: an MXFP8 output needs MXFP8 operands");
   const int force_tile = d->tile;
@@ -1743,7 +1949,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   // kernel reads back from the L2, keep plain stores
   a.nt_store = ((double)d->M * (d->epilogue == MJV_EPI_SILU_MUL ? d->N / 2 : d->N) * 2.0 >= 32.0 * 1024 * 1024) ? 1 : 0;
   if (MJV_TUNE(nt) >= 0) a.nt_store = MJV_TUNE(nt);
-  const bool big = force_tile ? force_tile == 256 : (d->M >= 512 && d->N >= 256);
+  const bool big = (force_tile && force_tile != 2) ? force_tile == 256 : (d->M >= 512 && d->N >= 256);
   hipStream_t s = (hipStream_t)stream;
   g_num_cus = mjv_device_cus();   // tail peeling and split-K plan against the CUs of THIS device (partitioned parts differ)
   const double flops = 2.0 * d->M * (double)d->N * d->K;
@@ -1773,6 +1979,25 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
   if (d->epilogue < 0 || d->epilogue > MJV_EPI_ROPE_QKV) {
     mjv_set_error("gemm: unknown epilogue %d", d->epilogue);
     return MJV_E_ARG;
+  }
+  // tile 2: the 128 x 256 two-workgroups-per-CU kernel (short-K Linears; every row in ONE launch: its last m-tile may be partial)
+  const bool t2_ok = (d->epilogue == MJV_EPI_BIAS || d->epilogue == MJV_EPI_BIAS_GELU || d->epilogue == MJV_EPI_SCALE_RES) && !d->out_rows &&
+                     d->out_group <= 0 && d->res_mod <= 0 && !d->row_scale && (uintptr_t)d->C % 16 == 0 && d->ldc % 8 == 0 &&
+                     (d->epilogue != MJV_EPI_SCALE_RES || (d->ldr % 8 == 0 && (uintptr_t)d->res % 16 == 0));
+  if (force_tile == 2) {
+    if (!t2_ok) {
+      mjv_set_error("gemm: tile 2 (128 x 256, two workgroups per CU) takes bias / bias + GELU / LayerScale + residual epilogues on plain, "
+                    "16-byte aligned output rows");
+      return MJV_E_UNSUPPORTED;
+    }
+    static const char* const tags2[] = {"gemm2_bias", "gemm2_bias_gelu", "", "gemm2_scale_res"};
+    a.gm = MJV_TUNE(gm) > 0 ? MJV_TUNE(gm) : 8;
+    MjvProfScope ps(tags2[d->epilogue], s, flops, bytes);
+    switch (d->epilogue) {
+      case MJV_EPI_BIAS: return launch_t2<MJV_EPI_BIAS>(a, s);
+      case MJV_EPI_BIAS_GELU: return launch_t2<MJV_EPI_BIAS_GELU>(a, s);
+      default: return launch_t2<MJV_EPI_SCALE_RES>(a, s);
+    }
   }
   // one profiler scope per kernel launch, named like the kernel rocprofv3 reports (t256::gemm256_kernel<EPI> / t128::...)
   // A 128-tile launch with fewer workgroups than the chip holds (the peeled tail rows, the batch-sized head GEMMs) is

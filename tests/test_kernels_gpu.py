@@ -189,6 +189,33 @@ def test_gemm_silu_mul(cuda, tile):
     assert_close_bf16(out, ref, 3, frac_exact=0.95, atol=2e-3, what="gemm_silu_mul")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 256), (65600 // 8, 1024, 1024), (300, 264, 64), (128, 256, 2048)])
+def test_gemm_two_per_cu_kernel_equals_the_256_tile(cuda, M, N, K):
+    """tile code 2 (round 6): the 128 x 256 x 32 kernel that runs two workgroups per CU - measured, not dispatched automatically
+    (profiles/r06_d_gemm_two_per_cu_ab.txt: 23-36 % slower than the 256 x 256 kernel) - sums k in the same 32-deep MFMA order as the
+    256-tile kernel, so its three epilogues (bias, bias + GELU on its 6-KiB sub-table, LayerScale + residual in place) must agree
+    with it BIT FOR BIT, ragged last m-tile and a column count that is no multiple of 256 included; other epilogues are refused."""
+    from mj_video_amd import ops, _lib
+    a, w = rnd(M, K, seed=1).to(cuda), rnd(N, K, std=0.05, seed=2).to(cuda)
+    bias, scale = rnd(N, std=0.2, seed=3).to(cuda), (1 + 0.1 * rnd(N, seed=4)).to(BF).to(cuda)
+    for epi, kw in ((_lib.EPI_BIAS, dict(bias=bias)), (_lib.EPI_BIAS_GELU, dict(bias=bias)), (_lib.EPI_SCALE_RES, dict(bias=bias, scale=scale))):
+        outs = []
+        for tile in (256, 2):
+            out = rnd(M, N, seed=5).to(cuda)        # (the residual stream for SCALE_RES, overwritten otherwise)
+            ops.gemm(a, w, out, epi, res=out if epi == _lib.EPI_SCALE_RES else None, tile=tile, **kw)
+            outs.append(out)
+        assert torch.isfinite(outs[1].float()).all()
+        assert torch.equal(outs[0], outs[1]), (epi, (outs[0].float() - outs[1].float()).abs().max().item())
+    x = (rnd(M, K, std=3.0, seed=7)).to(cuda)       # GELU over a wide range of pre-activations (|x| up to ~50 and tiny ones)
+    x[:, ::7] *= 1e-4
+    o256, o2 = torch.empty(M, N, dtype=BF, device=cuda), torch.empty(M, N, dtype=BF, device=cuda)
+    ops.gemm(x, w, o256, _lib.EPI_BIAS_GELU, bias=bias, tile=256)
+    ops.gemm(x, w, o2, _lib.EPI_BIAS_GELU, bias=bias, tile=2)
+    assert torch.equal(o256, o2)
+    with pytest.raises(_lib.MjvLibraryError, match="tile 2"):
+        ops.gemm(a, w, torch.empty(M, N, dtype=BF, device=cuda), _lib.EPI_BIAS_RELU, bias=bias, tile=2)
+
+
 @pytest.mark.parametrize("K", [256, 1024])
 @pytest.mark.parametrize("epi", ["bias", "silu_mul"])
 def test_gemm_persistent_equals_one_tile_kernel(cuda, epi, K):
