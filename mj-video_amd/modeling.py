@@ -819,21 +819,24 @@ class InternVLChatRewardModeling(nn.Module):
         if am is not None:
             if am.shape != ids.shape:
                 raise ValueError(f"attention_mask shape {am.shape} != input_ids shape {ids.shape}")
-            lens = am.sum(axis=1)
-            for b in range(B):
-                if not am[b, :lens[b]].all():
-                    raise NotImplementedError("only right-padded attention masks are supported (the reference's "
-                                              "collator and notebook right-pad: dataset.py:445-469)")
+            am = am.astype(bool)
         else:
-            lens = np.full(B, N, dtype=np.int64)
+            am = np.ones((B, N), dtype=bool)
+        # ANY mask (round 6; rounds 1-5 took right-padded ones only).  The reference's eager path adds a [B, 1, N, N] mask of
+        # {causal, key is valid} (modeling_internlm2.py:96-125,907-913) and numbers positions 0 .. N - 1 WITHOUT looking at the mask
+        # (:893-898): a valid query sees exactly the valid keys at or before its column, rotated by their COLUMN indices.  Packing the
+        # valid tokens of a row in column order, with those columns as positions, is the same computation - right padding, left
+        # padding or holes alike; rows at masked columns are garbage in the reference and are never read (the selected rows must be
+        # valid: checked below).
+        lens = am.sum(axis=1)
         if (lens <= 0).any():
             raise ValueError("empty sequence in the batch")
         vocab = self.model.language_model.model.tok_embeddings.weight.shape[0]
-        valid = ids if am is None else ids[am]
+        valid = ids[am]
         if valid.size and (int(valid.min()) < 0 or int(valid.max()) >= vocab):   # nn.Embedding raises here too
             raise IndexError(f"token id out of range [0, {vocab}): min {int(valid.min())}, max {int(valid.max())} "
                              "(tokenizer / checkpoint mismatch?)")
-        rs, gs, ctx = [], [], []
+        rs, gs, ctx, cols, loc = [], [], [], [], []
         for b in range(B):
             row = ids[b]
             if pad_id is None:
@@ -841,14 +844,17 @@ class InternVLChatRewardModeling(nn.Module):
             else:
                 r = (int(np.argmax(row == pad_id)) - 1) % N
             g = find_token_for_gating(row, getattr(self.config, "gating_token_pattern", None))
-            L = int(lens[b])
-            if r >= L or g >= L:
-                raise ValueError(f"sample {b}: reward row {r} / gating row {g} lies in the masked tail (valid length {L})")
-            if (row[L:] == ctx_id).any():
-                raise ValueError(f"sample {b}: <IMG_CONTEXT> tokens in the masked tail")
+            if not am[b, r] or not am[b, g]:
+                raise ValueError(f"sample {b}: reward row {r} / gating row {g} lies in the masked part of the sequence "
+                                 f"({int(lens[b])} valid tokens)")
+            c = np.flatnonzero(row == ctx_id)
+            if not am[b, c].all():
+                raise ValueError(f"sample {b}: <IMG_CONTEXT> tokens in the masked part of the sequence")
             rs.append(r)
             gs.append(g)
-            ctx.append(np.flatnonzero(row[:L] == ctx_id))
+            ctx.append(c)
+            cols.append(np.flatnonzero(am[b]))                   # valid columns, in order = the packed rows of this sample
+            loc.append(np.cumsum(am[b]) - 1)                     # column -> index among the valid ones
         n_ctx = sum(c.size for c in ctx)
         if n_ctx != n_tiles * self.model.num_image_token:
             raise ValueError(f"{n_ctx} <IMG_CONTEXT> tokens in input_ids but pixel_values holds {n_tiles} tiles x "
@@ -857,7 +863,10 @@ class InternVLChatRewardModeling(nn.Module):
         # the batch's common prompt prefix (system prompt + "Frame1: <img>": conversation.py:354-365, eval_genai_mjvideo.py:132-137)
         skip, prefix_ids = 0, None
         if prefix_lookup is not None:
-            lim = min(min(int(c[0]) if c.size else int(lens[b]) for b, c in enumerate(ctx)), min(rs), min(gs))
+            lim = min(min(int(c[0]) if c.size else N for c in ctx), min(rs), min(gs))
+            masked = np.flatnonzero(~am[:, :lim].all(axis=0))     # (a prefix column must be a valid token of every sample)
+            if masked.size:
+                lim = int(masked[0])
             if B > 1 and lim > 0:
                 differ = np.flatnonzero((ids[1:, :lim] != ids[0, :lim]).any(axis=0))
                 if differ.size:
@@ -872,20 +881,21 @@ class InternVLChatRewardModeling(nn.Module):
         cu, cu_tail = [0], [0]
         for b in range(B):
             row, L, r, g = ids[b], int(lens[b]), rs[b], gs[b]
-            base = cu[-1] - skip           # packed row of token j of this sample = base + j  (j >= skip)
-            reward_rows.append(base + r)
-            gating_rows.append(base + g)
-            packed.append(row[skip:L])
-            positions.append(np.arange(skip, L))
-            img_rows.append(base + ctx[b])
+            base = cu[-1] - skip           # packed row of the token at column j of this sample = base + loc[j]  (j >= skip)
+            lb = loc[b]
+            reward_rows.append(base + lb[r])
+            gating_rows.append(base + lb[g])
+            packed.append(row[cols[b][skip:]])
+            positions.append(cols[b][skip:])
+            img_rows.append(base + lb[ctx[b]])
             cu.append(base + L)
             # the rows from the first selected one on: all the last decoder layer needs QUERIES for (moe_reward.py:226-243)
-            t0 = min(r, g)
+            t0 = int(lb[min(r, g)])          # index among the valid tokens
             tb = cu_tail[-1] - t0
             tail_rows.append(base + np.arange(t0, L))
-            tail_pos.append(np.arange(t0, L))
-            sel_in_tail_r.append(tb + r)
-            sel_in_tail_g.append(tb + g)
+            tail_pos.append(cols[b][t0:])
+            sel_in_tail_r.append(tb + lb[r])
+            sel_in_tail_g.append(tb + lb[g])
             cu_tail.append(tb + L)
         return dict(B=B, N=N, total=cu[-1], max_len=int(lens.max()) - skip, skip=skip, prefix_ids=prefix_ids,
                     ids=np.concatenate(packed).astype(np.int32), positions=np.concatenate(positions).astype(np.int32),

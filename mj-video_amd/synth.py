@@ -283,6 +283,31 @@ def pad_batch(ids_list: List[torch.Tensor], pad_id: int = PAD_ID, length: Option
     return ids, mask
 
 
+def remask(ids: torch.Tensor, mask: torch.Tensor, mode: Optional[str], pad_id: int = PAD_ID):
+    """Re-arranges a right-padded batch for the mask cases of the fixtures: "left" = every shorter row LEFT-padded instead (valid
+    tokens at the end of the row); "holes" = three caption tokens of every row masked out in place (ids untouched); None = as is."""
+    if mode is None:
+        return ids, mask
+    ids, mask = ids.clone(), mask.clone()
+    if mode == "left":
+        N = ids.shape[1]
+        for b in range(ids.shape[0]):
+            L = int(mask[b].sum())
+            row = ids[b, :L].clone()
+            ids[b] = pad_id
+            ids[b, N - L:] = row
+            mask[b] = 0
+            mask[b, N - L:] = 1
+    elif mode == "holes":
+        for b in range(ids.shape[0]):
+            L = int(mask[b].sum())
+            for c in (L - 30, L - 21, L - 20):      # inside the 32 caption tokens that precede the 5-token gating pattern
+                mask[b, c] = 0
+    else:
+        raise ValueError(mode)
+    return ids, mask
+
+
 def stress_tensors(tensors: Dict[str, torch.Tensor], config, massive_frac: float = 0.01, massive_gain: float = 20.0,
                    logit_sigma: float = 10.0, fc1_sigma: float = 2.0, seed: int = 0) -> Dict[str, float]:
     """Re-scales random-init weights IN PLACE (``tensors``: checkpoint key -> tensor, e.g. ``dict(model.named_parameters())`` or a

@@ -84,8 +84,11 @@ def gen_tiny():
         ("batch2pad", 56, None, 13, [(2, 4, 3, None), (3, 2, 4, None)], None),
         ("interleave", 56, None, 14, [(4, 4, 5, 4)], None),
         ("img84", 84, None, 15, [(5, 2, 6, None)], None),
+        # round 6: masks other than right padding (modeling_internlm2.py:96-125,893-913: positions ignore the mask, keys obey it)
+        ("leftpad", 56, None, 17, [(6, 4, 7, None), (7, 2, 8, None)], "left"),
+        ("holes", 56, None, 18, [(8, 3, 9, None)], "holes"),
     ]
-    for name, S, vS, wseed, vids, _ in specs:
+    for name, S, vS, wseed, vids, mask_mode in specs:
         cd, hk, cfg = make_cfg("tiny", S, vS)
         sd32 = synth.synth_state_dict(cfg, seed=wseed, dtype=torch.float32)
         sd = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
@@ -96,12 +99,13 @@ def gen_tiny():
             ids_list.append(synth.synth_input_ids(n_img_tokens(cfg, nt), cs, interleave_frames=il))
         px = torch.cat(px_list)
         ids, mask = synth.pad_batch(ids_list)
+        ids, mask = synth.remask(ids, mask, mask_mode)
         ref = run_reference(model, px, ids, mask)
         probes = {}
         orc = ref_cpu.reward_forward(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID, probes=probes)
         check_equal(ref, orc, name)
         # per-sample batch-1 forwards must equal the padded batch rows
-        if len(vids) > 1:
+        if len(vids) > 1 and mask_mode is None:
             off = 0
             for b, (vi, nt, cs, il) in enumerate(vids):
                 one = run_reference(model, px[off:off + nt], ids_list[b], torch.ones_like(ids_list[b]))
@@ -116,7 +120,7 @@ def gen_tiny():
             arrays[f"{name}/fp32/{k}"] = v
         for k, v in probes.items():
             arrays[f"{name}/probe/{k}"] = v.float().numpy()
-        cases.append(dict(name=name, kind="tiny", image_size=S, vit_image_size=vS, weight_seed=wseed,
+        cases.append(dict(name=name, kind="tiny", image_size=S, vit_image_size=vS, weight_seed=wseed, mask_mode=mask_mode,
                           pixel_seed=100, videos=[dict(video_idx=a, n_tiles=b, caption_seed=c, interleave=d)
                                                   for a, b, c, d in vids]))
         print("tiny case", name, "score", ref["score"].tolist(), "fp32", f32["score"].tolist())

@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import FIELDS, ROOT, build_hip_model, case_inputs, load_golden, make_cfg
+from util import FIELDS, ROOT, build_hip_model, case_inputs, case_inputs_masked, load_golden, make_cfg
 
 pytestmark = pytest.mark.gpu
 TOL_FACTOR = 3.0
@@ -135,7 +135,7 @@ def test_tiny_cases_against_golden(cuda, scores, fused):
         model = build_hip_model(cfg, sd, cuda)
         model.attention_scores = scores
         model.norm_fusion = fused
-        px, ids, mask, _ = case_inputs(cfg, case["videos"], case["pixel_seed"], case["image_size"])
+        px, ids, mask, _ = case_inputs_masked(cfg, case)   # (round 6: "leftpad" / "holes" = masks other than right padding)
         model.debug_probes = {}
         out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
         torch.cuda.synchronize()
@@ -146,9 +146,8 @@ def test_tiny_cases_against_golden(cuda, scores, fused):
             ref = npz[f"{name}/probe/{key}"]
             got = t.float().cpu().numpy()
             if key.startswith("llm_"):
-                # golden is right-padded [B, N, C]; ours is packed
-                lens = [int(m.sum()) for m in mask]
-                ref = np.concatenate([ref[b, :lens[b]] for b in range(len(lens))], axis=0)
+                # golden is padded [B, N, C]; ours is packed: the rows at the valid columns, in order
+                ref = np.concatenate([ref[b][mask[b].bool().numpy()] for b in range(mask.shape[0])], axis=0)
             assert got.shape == ref.shape, (name, key, got.shape, ref.shape)
             err = rel_l2(got, ref)
             assert np.isfinite(got).all(), (name, key)

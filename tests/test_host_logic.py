@@ -314,9 +314,33 @@ def test_analyse_ids_packing():
     assert info["positions"][a.shape[1]] == 0
     with pytest.raises(ValueError, match="IMG_CONTEXT"):
         model._analyse_ids(ids.numpy(), mask.numpy().astype(bool), 5)
-    left = torch.flip(mask, dims=[1])
-    with pytest.raises(NotImplementedError, match="right-padded"):
-        model._analyse_ids(ids.numpy(), left.numpy().astype(bool), 6)
+    # a mask that hides a selected row or an <IMG_CONTEXT> token is refused
+    for col in (b.shape[1] - 1, b.shape[1] - 5, int(info["img_rows"][-1]) - a.shape[1]):
+        bad = mask.clone()
+        bad[1, col] = 0
+        with pytest.raises(ValueError, match="masked part"):
+            model._analyse_ids(ids.numpy(), bad.numpy().astype(bool), 6)
+    # ANY other mask is packed (round 6): LEFT padding - the reference's reward row is then the last column ((first pad) - 1 mod N),
+    # positions are the COLUMN indices (modeling_internlm2.py:893-898 numbers positions without looking at the mask)
+    pad = a.shape[1] - b.shape[1]
+    lids = ids.clone()
+    lids[1] = torch.cat([torch.full((pad,), synth.PAD_ID), b[0]])
+    lmask = mask.clone()
+    lmask[1] = torch.cat([torch.zeros(pad, dtype=mask.dtype), torch.ones(b.shape[1], dtype=mask.dtype)])
+    li = model._analyse_ids(lids.numpy(), lmask.numpy().astype(bool), 6)
+    assert li["cu"].tolist() == info["cu"].tolist() and (li["ids"] == info["ids"]).all()
+    assert li["positions"][a.shape[1]:].tolist() == list(range(pad, a.shape[1]))
+    assert li["sel_rows"].tolist() == info["sel_rows"].tolist() and (li["img_rows"] == info["img_rows"]).all()
+    # ... and holes: two caption tokens of sample a masked out - they leave the packed rows, the later tokens keep their columns
+    hmask = mask.clone()
+    hole = [a.shape[1] - 12, a.shape[1] - 9]
+    hmask[0, hole] = 0
+    hi = model._analyse_ids(ids.numpy(), hmask.numpy().astype(bool), 6)
+    keep = [c for c in range(a.shape[1]) if c not in hole]
+    assert hi["cu"].tolist() == [0, a.shape[1] - 2, a.shape[1] - 2 + b.shape[1]]
+    assert hi["positions"][:a.shape[1] - 2].tolist() == keep and (hi["ids"][:a.shape[1] - 2] == a[0, keep].numpy()).all()
+    assert hi["sel_rows"].tolist() == [a.shape[1] - 3, a.shape[1] - 2 + b.shape[1] - 1, a.shape[1] - 7, a.shape[1] - 2 + b.shape[1] - 5]
+    assert hi["tail_pos"][:5].tolist() == list(range(a.shape[1] - 5, a.shape[1]))
     model.model.img_context_token_id = None
     with pytest.raises(ValueError, match="img_context_token_id"):
         model._analyse_ids(ids.numpy(), mask.numpy().astype(bool), 6)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import FIELDS, case_inputs, load_golden, make_cfg
+from util import FIELDS, case_inputs, case_inputs_masked, load_golden, make_cfg
 from mj_video_amd import synth
 from oracle import ref_cpu
 
@@ -43,7 +43,7 @@ def test_oracle_reproduces_reference_tiny():
         cfg = make_cfg("tiny", case["image_size"], case["vit_image_size"])
         sd = synth.synth_state_dict(cfg, seed=case["weight_seed"], dtype=torch.float32)
         sd = {k: v.to(torch.bfloat16) for k, v in sd.items()}
-        px, ids, mask, _ = case_inputs(cfg, case["videos"], case["pixel_seed"], case["image_size"])
+        px, ids, mask, _ = case_inputs_masked(cfg, case)     # (incl. the left-padded and the holey mask of round 6)
         probes = {}
         out = ref_cpu.reward_forward(sd, cfg, px, ids, mask, synth.IMG_CONTEXT_ID, synth.PAD_ID, probes=probes)
         n_exact += _check(out, npz, case["name"], names)

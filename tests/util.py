@@ -37,6 +37,13 @@ def case_inputs(cfg, case_videos, pixel_seed, image_size):
     return torch.cat(px), ids_b, mask, ids
 
 
+def case_inputs_masked(cfg, case, pixel_seed=None):
+    """``case_inputs`` + the fixture case's mask arrangement (tests/golden/make_golden.py "mask_mode": left padding, holes)"""
+    px, ids_b, mask, ids = case_inputs(cfg, case["videos"], case["pixel_seed"] if pixel_seed is None else pixel_seed, case["image_size"])
+    ids_b, mask = synth.remask(ids_b, mask, case.get("mask_mode"))
+    return px, ids_b, mask, ids
+
+
 def apply_test_overrides(model):
     """MJV_TEST_ATTENTION_SCORES=eager|flash runs the model-level parity tests under the other attention numerics (the gate of
     DESIGN §4 "Attention, round 4": both settings are held to the same fixtures); unset = the model's default"""
