@@ -13,7 +13,8 @@ extern "C" {
 #endif
 
 /* GEMM: 0 resets everything.  4000 / 4001 split-K of 128-tile launches off / on; 4200 / 4201 K-sliced 256-tile launches off / on;
- * 4100 + s caps the slices per tile at s (1..8); 4300 + n sets the fewest K-tiles per 256-tile slice; 2000 + g forces the
+ * 4100 + s caps the slices per tile at s (1..8); 4300 + n sets the fewest K-tiles per 256-tile slice; 4400 + n the fewest K-tiles
+ * of a problem that may run K-sliced on 256 tiles at all (default 64 = K >= 4096); 2000 + g forces the
  * group-M of the tile order (2000 = per shape); 6000 + m = largest M the skinny kernel takes (6000 = never);
  * 7000 / 7001 / 7002 streaming (nt) output stores by shape / never / always;
  * 1000 / 1003 / 1004 / 1006 select the 256-tile kernel's variants (1003: no epilogue, 1004: no global stores - wrong results;

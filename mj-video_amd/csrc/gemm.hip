@@ -1709,6 +1709,7 @@ struct GemmTune {
   int variant = 0;          // 256-tile kernel variant (3: no epilogue, 4: no global stores, 6: s_memtime stamps)
   int split256_min_kt = 8;  // fewest K-tiles per slice of the K-sliced 256-tile launches
   int split256 = 1;         // under-filled problems with deep K run as K slices of 256 x 256 tiles
+  int split256_min_nk = 64; // ... deep = at least this many 64-wide K-tiles (bench: 4400 + n)
   int nt = -1;              // streaming output stores: -1 = by shape, 0 / 1 = never / always
   void* stamp_buffer = nullptr;
 };
@@ -1876,6 +1877,7 @@ extern "C" int mjv_bench_gemm_set(int32_t code) {
   if (code > 4100 && code <= 4108) { g_tune.split_max = code - 4100; return MJV_OK; }
   if (code >= 6000 && code <= 6512) { g_tune.skinny_max_m = code - 6000; return MJV_OK; }   // 6000 switches the skinny kernel off
   if (code > 4300 && code <= 4364) { g_tune.split256_min_kt = code - 4300; return MJV_OK; }
+  if (code > 4400 && code <= 4528) { g_tune.split256_min_nk = code - 4400; return MJV_OK; }
   if (code == 4200 || code == 4201) { g_tune.split256 = code - 4200; return MJV_OK; }
   if (code == 4000 || code == 4001) { g_tune.split_k = code - 4000; return MJV_OK; }
   if (code >= 2000 && code < 2100) { g_tune.gm = code - 2000; return MJV_OK; }               // 2000: back to the per-shape choice
@@ -2029,7 +2031,7 @@ extern "C" int mjv_gemm_bf16(const mjv_gemm_desc* d, void* stream) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), nk = g.K / 64;
     // (a last m-tile that is mostly empty wastes its share of every slice: 138 rows x 16384 columns ran 10 % slower sliced)
     const bool filled = (long)g.M * 10 >= (long)((g.M + 255) / 256) * 256 * 7;
-    if (g.M <= MJV_TUNE(skinny_max_m) || g.N < 256 || nk < 64 || tiles * 2 > g_num_cus || !filled) return false;
+    if (g.M <= MJV_TUNE(skinny_max_m) || g.N < 256 || nk < MJV_TUNE(split256_min_nk) || tiles * 2 > g_num_cus || !filled) return false;
     int sp = g_num_cus / tiles;
     if (sp > MJV_TUNE(split_max)) sp = MJV_TUNE(split_max);
     if (sp > nk / MJV_TUNE(split256_min_kt)) sp = nk / MJV_TUNE(split256_min_kt);

@@ -653,13 +653,21 @@ def test_prefix_cache_is_invisible_and_invalidates(cuda, fmt):
     sliced = model.forward(px, ids, mask)
     assert fields_equal(cold, sliced) == []          # cold and warm cache: the same computation
     assert model._prefix["settings"][6] is True
+    # (bounds derived, not fitted.  bf16: a cached and an uncached evaluation are two samples of the rounding noise the
+    # reference's bf16 run carries against its fp32 run at these dims - 2B dims @224^2: the full_c1 fixture - and two samples differ
+    # by sqrt(2) x one: bound 1.5 x the fixture's largest bf16-vs-fp32 distance of the row, the bound _full_case holds the HIP path
+    # itself to.  mxfp8: a re-associated sum moves some FFN inputs across an e4m3 rounding boundary (2^-3 of the element, not 2^-8), so
+    # two fp8 evaluations that slice K differently differ like two fp8 IMPLEMENTATIONS do: test_fp8_gpu.py holds those to 0.75 x the
+    # oracles' fp8-vs-bf16 gap at these very dims (18.5 % / 19.7 % of the rows' norm: 0.139) - the same bound here.  Measured in round
+    # 5: 2.9 % / 8.6 %; the values of every run are printed.)
+    gnpz, gmeta = load_golden("full_c1")
     for f in ("hidden_state", "prompt_embedding"):
         e = rel_l2(getattr(sliced, f).float().cpu().numpy(), getattr(plain, f).float().cpu().numpy())
-        print(f"prefix cache on vs off, K-slicing on, {fmt}, {f}: relative L2 {e:.4f}")
-        # bf16: as above.  mxfp8: a re-associated sum moves some FFN inputs across an e4m3 rounding boundary (2^-3 of the element, not
-        # 2^-8) - two fp8 evaluations that slice K differently (the row count decides which tail rows run K-sliced) differ like two
-        # fp8 implementations do (test_fp8_gpu.py: 12 % end to end at these dims; measured here 8.6 %)
-        assert e < (0.045 if fmt == "bf16" else 0.15), (f, e)
+        own = max(rel_l2(gnpz[f"v{v['video_idx']}/{f}"], gnpz[f"v{v['video_idx']}/fp32/{f}"]) for v in gmeta["videos"]
+                  if f"v{v['video_idx']}/fp32/{f}" in gnpz.files)
+        bound = 1.5 * own if fmt == "bf16" else 0.75 * 0.185
+        print(f"prefix cache on vs off, K-slicing on, {fmt}, {f}: relative L2 {e:.4f} (bound {bound:.4f}; the reference's own bf16-vs-fp32 {own:.4f})")
+        assert e < bound, (f, e, bound)
 
 
 def test_stressed_statistics_tiny_against_oracle(cuda):

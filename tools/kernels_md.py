@@ -22,29 +22,29 @@ def load_line(path):
 # kernel tag -> (what it is, shapes at the headline workload, bound, peak for `frac`, the ONE reason it is not faster, DESIGN anchor)
 ROWS = [
     ("gemm256_scale_res", "256² tile GEMM, bias·LayerScale + residual epilogue", "ViT proj 65 536×1024×1024, fc2 65 536×1024×4096; LLM wo 16 384×2048×2048, w2 16 384×2048×8192 (main rows)", "MFMA", 2500,
-     "main loop at 0.85-0.96 of what the 1.7-1.9 GHz the chip holds allows; the residual epilogue (64 residual registers, LDS round trip) is not overlapped by MFMA work: 1 workgroup per CU owns all 160 KiB", "§4 Measured r4 'the clock'; §7.1"),
+     "main loop at 0.85-0.96 of what the 1.7-1.9 GHz the chip holds allows; the residual epilogue (64 residual registers, LDS round trip) is not overlapped by MFMA work: 1 workgroup per CU owns all 160 KiB (round 6: the 128 × 256 two-per-CU form that does overlap it - epilogue 4 % of a tile - was built and measured 23-36 % slower: its main loop runs at 0.68 ×)", "docs/rounds/r04.md 'the clock'; r06.md §3"),
     ("gemm256_silu_mul", "256² GEMM, SiLU(w1 x)·(w3 x) epilogue, persistent form", "LLM w1∣w3 16 976×16 384×2048", "MFMA", 2500,
-     "same main loop; last round 75 % full (67 × 64 tiles = 16.75 rounds) and 5.5 × the algorithmic fabric bytes (tile order floor)", "§4 r3 'persistent'"),
+     "same main loop; last round 75 % full (67 × 64 tiles = 16.75 rounds) and 5.5 × the algorithmic fabric bytes (tile order floor)", "docs/rounds/r03.md 'persistent'; DESIGN §9"),
     ("gemm256_bias_gelu", "256² GEMM, bias + exact-erf GELU by table", "ViT fc1 65 536×4096×1024", "MFMA", 2500,
-     "K = 1024 is 16 K-tiles per tile, so the epilogue is ⅓ of a tile's life; 128 LDS table gathers per lane (≈ 9 LDS cycles each: random banks) + 5.5 vector instr. per element that no MFMA overlaps", "§4 r4 'GELU'; §6e item 6"),
+     "K = 1024 is 16 K-tiles per tile, so the epilogue is ⅓ of a tile's life; 128 LDS table gathers per lane (≈ 9 LDS cycles each: random banks) + 5.5 vector instr. per element that no MFMA overlaps (beside a neighbour's main loop, in the two-per-CU form, the GELU still costs 20 %: round 6)", "docs/rounds/r04.md 'GELU'; r06.md §3"),
     ("gemm256_bias", "256² GEMM, bias epilogue, persistent form", "ViT qkv 65 536×3072×1024; projector", "MFMA", 2500,
-     "short K (16 K-tiles): prologue + epilogue ≈ 20 % of a tile even with the next tile's first K-tile prefetched under the epilogue", "§4 r3 'persistent'"),
+     "short K (16 K-tiles): prologue + epilogue ≈ 20 % of a tile even with the next tile's first K-tile prefetched under the epilogue", "docs/rounds/r03.md 'persistent'; DESIGN §9"),
     ("gemm256_rope_qkv", "256² GEMM, rotary embedding + GQA de-interleave epilogue", "LLM wqkv 16 384×4096×2048 (23 layers), last layer k∣v 16 384×2048×2048", "MFMA", 2500,
-     "two dependent table fetches (position → cos / sin rows) per pass in the epilogue; no persistent form (its LDS window is the whole tile)", "§4 r2 'RoPE epilogue'"),
+     "two dependent table fetches (position → cos / sin rows) per pass in the epilogue; no persistent form (its LDS window is the whole tile)", "docs/rounds/r02.md"),
     ("attn_d64", "flash-style attention, D = 64, non-causal, 64 seq × 16 heads × 1025", "ViT, 24 layers", "MFMA (VALU-issue limited)", 2500,
-     "6 vector instructions per score pair, 4 of the 8 issue slots are the two v_exp_f32: the softmax, not the MFMA, sets the pace at D = 64; + one extra block per (sequence, head) for query 0 (0.8 ms per step gross)", "§4 'Attention, round 3 / 4'"),
+     "6 vector instructions per score pair, 4 of the 8 issue slots are the two v_exp_f32: the softmax, not the MFMA, sets the pace at D = 64 (moving the row sum onto the MFMA pipe makes the matrix pipe the longer one: round 6); + one extra block per (sequence, head) for query 0 (0.8 ms per step gross)", "DESIGN §4.3; docs/rounds/r03.md, r04.md, r06.md §4"),
     ("attn_d128_causal", "flash-style attention, D = 128, causal GQA, 8 seq × 16/8 heads × 2122 (+64 cached prefix keys)", "LLM, 24 layers (last: 5 queries per sequence)", "MFMA + VALU", 2500,
-     "one 32-query sub-block per wave (two would need ≈ 310 registers): MFMA and softmax of one unit serialise more than at D = 64; diagonal tiles run the masked general path", "§4 'Attention, round 3 / 4'"),
+     "one 32-query sub-block per wave (two would need ≈ 310 registers): MFMA and softmax of one unit serialise more than at D = 64; diagonal tiles run the masked general path", "DESIGN §4.3; docs/rounds/r03.md, r04.md, r06.md §4"),
     ("layernorm", "LayerNorm 1024, one wave per row", "ViT norm1 / norm2, 65 600 rows × 48", "HBM", 8000,
-     "4 B per element of traffic at 5.7-5.9 TB/s = the 6.3 TB/s this chip's HBM delivers to any kernel; only folding it into the GEMM removes it (built: model.norm_fusion, off for parity)", "§4 'Norm fusion, round 4'"),
+     "4 B per element of traffic at 5.7-5.9 TB/s = the 6.3 TB/s this chip's HBM delivers to any kernel; only folding it into the GEMM removes it (built: model.norm_fusion, off for parity)", "docs/rounds/r04.md 'Norm fusion'"),
     ("rmsnorm", "RMSNorm 2048 (cast before gain), one wave per row", "LLM attention_norm / ffn_norm, 16 976 rows × 48", "HBM", 8000,
      "as layernorm (5.0 TB/s: shorter launch, 35 MB per launch sits partly in the Infinity Cache)", "same"),
     ("gemm256s_scale_res", "K-sliced 256² GEMM + finish kernel", "LLM w2 tail: 592 rows × 2048 × 8192 in 8 slices", "MFMA / fabric", 2500,
-     "a tail: 24 tiles cannot fill 256 CUs without slicing K, and the slices' fp32 images make a 50 MB round trip", "§4 'Tails, revisited'"),
+     "a tail: 24 tiles cannot fill 256 CUs without slicing K, and the slices' fp32 images make a 50 MB round trip", "docs/rounds/r03.md, r05.md 'Tails'; DESIGN §9"),
     ("gemm64_scale_res", "64×32 skinny GEMM", "ViT proj / fc2 tails: the 64 CLS rows of M = 65 600 = 256·256 + 64 (48 launches), last-layer rows", "latency", 2500,
-     "32 workgroups each walk K / 64 dependent LDS fills (≈ 20 µs at K = 4096): latency-bound by construction", "§4 r2 'skinny'"),
+     "32 workgroups each walk K / 64 dependent LDS fills (≈ 20 µs at K = 4096): latency-bound by construction", "docs/rounds/r02.md"),
     ("gemm128_bias", "128² GEMM (+ rope_split)", "LLM wqkv tail 592 × 4096 × 2048; heads", "L2→LDS fill", 2500,
-     "160 workgroups, one per CU, double-buffered only: ≈ 45 GB/s of LDS fill per CU; K-slicing at K = 2048 is a wash (measured r3)", "§4 'Tails, revisited'"),
+     "160 workgroups, one per CU, double-buffered only: ≈ 45 GB/s of LDS fill per CU; K-slicing at K = 2048 is a wash (measured r3)", "docs/rounds/r03.md, r05.md 'Tails'; DESIGN §9"),
     ("gemm128_scale_res", "128² GEMM, residual epilogue", "LLM wo tail 592 × 2048 × 2048", "L2→LDS fill", 2500, "as gemm128_bias", "same"),
     ("gemm64_bias_gelu", "64×32 skinny GEMM", "ViT fc1 tail (64 CLS rows)", "latency", 2500, "as gemm64_scale_res", "same"),
     ("gemm64_bias", "64×32 skinny GEMM", "ViT qkv tail (64 CLS rows), gating layers", "latency", 2500, "as gemm64_scale_res", "same"),
@@ -89,9 +89,11 @@ def main():
     w = out.append
     w("# KERNELS — state of the kernels on one page\n")
     w(f"Headline workload (BASELINE.json configs[1]: 4 pairs = 8 videos × 8 frames @448², N = 2186 tokens per video, bf16, 1 MI355X): "
-      f"**{line['value']:.2f} pairs/s, {line['ms_per_step']:.2f} ms per step = {line['frac_of_mfma_roofline']:.3f} of the 96.9 pairs/s MFMA roofline** "
-      f"(`{os.path.relpath(sys.argv[1], ROOT)}`, a box of this round's pool; prefix cache "
-      f"{'on' if line['config'].get('prefix_cache') else 'off'}, last-layer query trimming {'on' if line['config'].get('trim_last_layer') else 'off'})."
+      f"**{line['value']:.2f} pairs/s, {line['ms_per_step']:.2f} ms per step = {line['frac_of_mfma_roofline']:.3f} of the 2.5 PFLOP/s MFMA peak on the "
+      f"{line.get('executed_tflop_per_pair', 25.8)} TFLOP per pair it EXECUTES** (25.8 algorithmic: 96.9 pairs/s at the peak; prefix cache "
+      f"{'on' if line['config'].get('prefix_cache') else 'off'}, last-layer query trimming {'on' if line['config'].get('trim_last_layer') else 'off'}); "
+      f"every row in every forward (`value_all_work`): **{line.get('value_all_work')} pairs/s = {line.get('frac_all_work')}** "
+      f"(`{os.path.relpath(sys.argv[1], ROOT)}`, a box of this round's pool)."
       + (f" The driver's own record: **{drv['value']:.2f} pairs/s** (`{os.path.basename(sys.argv[2])}`)." if drv else "") + "\n")
     w("Every kernel is hand-written HIP for gfx950 (`mj-video_amd/csrc/`). Columns: time per 4-pair step from the profiled step of that "
       "bench line (HIP events around every launch), achieved rate, fraction of the peak that bounds it (2.5 PFLOP/s dense bf16 MFMA, "
@@ -124,7 +126,16 @@ def main():
             if r:
                 w(f"| `{tag}` | {what}; {shapes} | {r['ms_per_step']:.2f} | {r['tflops']:.0f} | {r['tflops'] / peak:.2f} | {why} |")
         w("\nThe four attention-side Linears stay bf16: each of them on MXFP8 operands adds noise and none keeps 0 flips "
-          "(`profiles/r05_c_fp8_per_linear_study.txt`, DESIGN §4 'fp8, round 5').\n")
+          "(`profiles/r05_c_fp8_per_linear_study.txt`).  Which FFN Linear carries the rank noise, and the presets that follow "
+          "(`profiles/r06_a_fp8_ffn_subset_study.txt`, DESIGN §5):\n")
+        w("| preset | fp8 Linears | pairs/s | ms per step | Spearman vs the reference's bf16 scores @224² / @448² | decisive flips |")
+        w("|---|---|---|---|---|---|")
+        for leg, preset, lin, rho in (("fp8_rank999", "mxfp8-rank999", "fc1, fc2, w2", "0.99920 / 0.99912 (north_star's bar: ≥ 0.999)"),
+                                      ("fp8_ffn", "mxfp8", "fc1, fc2, w1∣w3, w2", "0.99863 / 0.99820 (its own stated tolerance)")):
+            r = sec.get(leg) or {}
+            if r.get("value"):
+                w(f"| `{preset}` | {lin} | {r['value']:.2f} | {r['ms_per_step']:.1f} | {rho} | 0 / 0 |")
+        w("")
     w("## The other configs of BASELINE.json, same process (`secondary`)\n")
     w("| leg | config | pairs/s | ms per step | of its MFMA roofline |")
     w("|---|---|---|---|---|")
@@ -134,8 +145,22 @@ def main():
         r = sec.get(name) or {}
         if r.get("value"):
             w(f"| `{name}` | {label} | {r['value']:.2f} | {r['ms_per_step']:.1f} | {r.get('frac_of_mfma_roofline', '-')} |")
+    c5 = sec.get("c5_4b") or {}
+    if c5.get("value"):
+        w(f"\n## BASELINE configs[4]: the InternVL2-4B backbone (InternViT + Phi-3-mini, {c5['parameters_G']} G parameters; `secondary.c5_4b`)\n")
+        w(f"4 pairs × 8 frames @448², N = {c5['N']}, one MI355X; {c5['algorithmic_tflop_per_pair']} algorithmic TFLOP per pair = {c5['roofline_pairs_per_s_bf16']} pairs/s at "
+          "the bf16 MFMA peak.  Oracle: `oracle/ref_phi3.py`, pinned to transformers 5.15's `Phi3ForCausalLM` run inside the reference's reward model.\n")
+        w("| format | pairs/s | ms per step | of the bf16 MFMA roofline | largest kernels (ms per step, TFLOP/s) |")
+        w("|---|---|---|---|---|")
+        for name, label in (("bf16", "bf16"), ("fp8_rank999", "`mxfp8-rank999`"), ("fp8_ffn", "`mxfp8`")):
+            r = c5.get(name) or {}
+            if r.get("value"):
+                top = "; ".join(f"`{t}` {v['ms_per_step']:.1f}" + (f" @ {v['tflops']:.0f}" if v.get('tflops') else "") for t, v in list(r["kernels"].items())[:6])
+                w(f"| {label} | {r['value']:.2f} | {r['ms_per_step']:.1f} | {r['frac_of_bf16_mfma_roofline']} | {top} |")
+        w("\n`attn_d96_causal` = the head_dim 96 instantiation of the attention kernel (ABI 7); `rope_heads` = the rotary embedding in place on "
+          "`qkv_proj`'s [q ∣ k ∣ v] columns (HBM-bound, not fused: DESIGN §5, docs/rounds/r06.md §2).")
     w("\nNot on this page because they are not on the scoring path's clock: `preprocess.hip` (device-side `load_video` resize: 0.44 ms per "
-      "128 720p frames, DESIGN §6b), `mxfp8.hip` (weights quantised once).")
+      "128 720p frames, docs/rounds/r04.md), `mxfp8.hip` (weights quantised once).")
     open(os.path.join(ROOT, "KERNELS.md"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
