@@ -428,6 +428,8 @@ def main():
         model.set_ffn_format("mxfp8")
     if args.no_prefix_cache:
         model.prefix_cache = model.trim_last_layer = False
+    if os.environ.get("MJV_BENCH_VIT_CHUNK"):     # A/B (round 6): the vision tower over this many tiles at a time
+        model.vit_chunk_tiles = int(os.environ["MJV_BENCH_VIT_CHUNK"])
     if os.environ.get("MJV_BENCH_NORM_FUSION"):   # A/B of DESIGN "Norm fusion, round 4" (never a reported headline: the line says so)
         model.norm_fusion = True
     for code in args.gemm_code:   # (bench build of the library only: MJV_LIBRARY=.../libmjv_hip_bench.so)
@@ -520,7 +522,7 @@ def main():
             "data": "synthetic", "ranks_seen": ranks_seen,
             "ms_per_step_by_rank": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
                                     "all": [round(x, 3) for x in rank_ms]},
-            "norm_fusion": bool(model.norm_fusion),
+            "norm_fusion": bool(model.norm_fusion), "vit_chunk_tiles": getattr(model, "vit_chunk_tiles", None),
             "attention_scores": model.attention_scores,
             "process_group": ("nccl" if use_dist else None),
             "config": {"workload": (f"MJ-VIDEO-2B, batch={args.pairs * world} pairs"
@@ -627,7 +629,7 @@ def main():
                                "pairs_per_s_at_batch_1_video": round(0.5e3 / lat_ms, 3),
                                "note": "back-to-back single-video forwards, not part of `value`"}
         if (world == 1 and not use_dist and not args.no_secondary and not args.fp8 and (S, F, args.pairs) == (448, 8, 4)
-                and not os.environ.get("MJV_BENCH_NORM_FUSION") and not args.gemm_code):
+                and not os.environ.get("MJV_BENCH_NORM_FUSION") and not os.environ.get("MJV_BENCH_VIT_CHUNK") and not args.gemm_code):
             line["secondary"] = secondary_legs(model, cfg, dev, px, ids, mask)
             off = line["secondary"].get("prefix_cache_off")
             if off and off.get("value"):

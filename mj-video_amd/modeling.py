@@ -912,14 +912,33 @@ class InternVLChatRewardModeling(nn.Module):
 
     def _vision_tower_launch(self, d, pixel_values: torch.Tensor):
         """Everything of the vision tower that needs no token ids: patchify -> 24 x ViT layer -> pixel-shuffle + LayerNorm +
-        first projector layer.  Returns what ``_vision_tower_splice`` needs."""
+        first projector layer.  Returns what ``_vision_tower_splice`` needs.  ``vit_chunk_tiles`` (measurement switch, default
+        None = all tiles in one pass): the tower over that many tiles at a time, every chunk through the SAME scratch buffers -
+        tiles are independent of one another, so only the launch sizes change."""
+        dev = pixel_values.device
+        vc = self.config.vision_config
+        tiles, _, S, _ = pixel_values.shape
+        P = vc.patch_size
+        if S % P or (S // P) % 2:
+            raise ValueError(f"image size {S} must be an even multiple of the patch size {P}")
+        G = S // P
+        per = (G // 2) ** 2
+        mlp1 = self.model.mlp1
+        ph = self._buf("proj_h", tiles * per, mlp1[1].out_features, dev)
+        chunk = getattr(self, "vit_chunk_tiles", None) or tiles
+        if self.debug_probes is not None:
+            chunk = tiles            # (the per-layer probes hold every tile)
+        for c0 in range(0, tiles, chunk):
+            c1 = min(tiles, c0 + chunk)
+            self._vision_tower_chunk(d, pixel_values[c0:c1], ph[c0 * per:c1 * per])
+        return ph, tiles
+
+    def _vision_tower_chunk(self, d, pixel_values: torch.Tensor, ph: torch.Tensor):
         dev = pixel_values.device
         vc = self.config.vision_config
         vm = self.model.vision_model
         tiles, _, S, _ = pixel_values.shape
         P, dim, ff, H = vc.patch_size, vc.hidden_size, vc.intermediate_size, vc.num_attention_heads
-        if S % P or (S // P) % 2:
-            raise ValueError(f"image size {S} must be an even multiple of the patch size {P}")
         G = S // P
         npatch, T = G * G, G * G + 1
         rows = tiles * T
@@ -949,9 +968,7 @@ class InternVLChatRewardModeling(nn.Module):
         ntok = tiles * (G // 2) ** 2
         pl = self._buf("proj_ln", ntok, 4 * dim, dev)
         ops.layernorm(x, mlp1[0].weight, mlp1[0].bias, pl, mlp1[0].eps, rows=ntok, gather_grid=G)
-        ph = self._buf("proj_h", ntok, mlp1[1].out_features, dev)
         ops.gemm(pl, mlp1[1].weight, ph, EPI_BIAS_GELU, bias=mlp1[1].bias)
-        return ph, tiles
 
     def _vision_tower_splice(self, vit, hidden: torch.Tensor, img_rows: torch.Tensor):
         """second projector layer, its rows written straight into the <IMG_CONTEXT> rows of ``hidden``

@@ -42,6 +42,8 @@ def gemm_case():
         return
     epi = rng.choice(["bias", "nobias", "gelu", "relu", "scale_res", "res", "silu"])
     tile = rng.choice([0, 0, 0, 64, 128, 256])
+    if epi in ("bias", "nobias", "gelu", "scale_res", "res") and rng.random() < 0.25:
+        tile = 2                      # (round 6) the 128 x 256 two-workgroups-per-CU kernel: its three epilogues, plain rows
     use_ws = rng.random() < 0.5
     integer = rng.random() < 0.4 and epi in ("bias", "nobias", "relu")
     lda = K + 8 * rng.choice([0, 0, 1, 5])
@@ -109,7 +111,7 @@ def gemm_case():
 
 
 def attn_case():
-    D = rng.choice([64, 128])
+    D = rng.choice([64, 128, 96])         # 96 (round 6, ABI 7): Phi-3-mini's heads, round-3 kernel only
     causal = rng.random() < 0.5
     G = rng.choice([1, 1, 2, 4])
     KVH = rng.choice([1, 2, 4])
@@ -124,8 +126,10 @@ def attn_case():
     mode = rng.choice([0, 1, 2])         # 2 (round 4): unrounded fp32 scores, the round-3 kernel only
     scale = D ** -0.5 if rng.random() < 0.8 else 0.1
     kern = rng.choice([0, 0, 0, 4, 5, 6, 7]) if mode != 2 else rng.choice([0, 0, 6, 7])
-    if kern == 6 and D == 128:           # (the two-wave form exists at head_dim 64 only: MJV_E_UNSUPPORTED at 128)
+    if kern == 6 and D != 64:            # (the two-wave form exists at head_dim 64 only: MJV_E_UNSUPPORTED at 96 / 128)
         kern = 7
+    if D == 96 and kern in (4, 5):
+        kern = 0
     std = rng.choice([1.0, 1.0, 2.5])
     qkv = (torch.randn(N, (H + 2 * KVH) * D, device=dev) * std).to(BF)       # q / k / v as column slices (row stride != width)
     q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KVH) * D], qkv[:, (H + KVH) * D:]
@@ -173,7 +177,7 @@ def attn_case():
 def attn_ext_case():
     """ABI 6 (round 5): causal launches with suffix queries (cu_seqlens_q) and / or a shared key / value prefix, against the ordinary
     launch of the same kernel over the concatenated rows [prefix | own] - bit for bit (same key tiles, same arithmetic)"""
-    D = rng.choice([64, 128])
+    D = rng.choice([64, 128, 96])
     G = rng.choice([1, 2, 4])
     KVH = rng.choice([1, 2])
     H = KVH * G
