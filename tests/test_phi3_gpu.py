@@ -204,6 +204,36 @@ def test_phi3_tiny_cases_against_golden(cuda, scores):
     print("worst probe errors:", sorted(report, key=lambda r: -r[2])[:5])
 
 
+@pytest.mark.parametrize("kv_heads,mask_mode", [(1, None), (2, "left"), (4, "holes")])
+def test_phi3_gqa_and_masks_against_the_oracle(cuda, kv_heads, mask_mode):
+    """what the fixtures do not hold, against the ORACLE (pinned to transformers for the MHA cases) on the same seeded inputs at
+    tiny dims: grouped-query heads (4 query heads over 1 / 2 / 4 key-value heads: modeling_phi3.py repeat_kv) and the masks other
+    than right padding (left padding, holes: shared host code with the InternLM2 tower, whose reference-executed cases pin it).
+    Bounds: the tiny cases' (3 x the fixture's noise floor per field, 3 % on the hidden rows)."""
+    from mj_video_amd import synth
+    from oracle import ref_phi3
+    npz, meta = load_golden("phi3_tiny")
+    names = [c["name"] for c in meta["cases"]]
+    cfg = phi3_cfg("tiny", 56, hidden_size=384, num_attention_heads=4, num_key_value_heads=kv_heads)
+    sd = synth.synth_state_dict(cfg, seed=40 + kv_heads)
+    model = build_phi3_model(cfg, sd, cuda)
+    model.attention_scores = "eager"          # the oracle's numerics
+    vids = [dict(video_idx=0, n_tiles=4, caption_seed=1), dict(video_idx=1, n_tiles=2, caption_seed=2)]
+    px, ids, mask = phi3_inputs(cfg, vids, 300, 56)
+    ids, mask = synth.remask(ids, mask, mask_mode, pad_id=synth.PHI3_TOKENS.pad)
+    out = model.forward(px.to(cuda), ids.to(cuda), mask.to(cuda))
+    torch.cuda.synchronize()
+    ref = ref_phi3.reward_forward(sd, cfg, px, ids, mask, synth.PHI3_TOKENS.img_context, synth.PHI3_TOKENS.pad, cfg.gating_token_pattern)
+    for f in FIELDS:
+        got, want = getattr(out, f).float().cpu().numpy(), ref[f].float().numpy()
+        assert got.shape == want.shape, (f, got.shape, want.shape)
+        if f in ("hidden_state", "prompt_embedding"):
+            assert rel_l2(got, want) < 0.03, (f, rel_l2(got, want))
+            continue
+        tol = TOL_FACTOR * noise_floor(npz, names, f) + ATOL_FLOOR
+        assert float(np.abs(got - want).max()) <= tol, (f, float(np.abs(got - want).max()), tol)
+
+
 def test_phi3_errors_and_pattern(cuda):
     """the gating rows are found by config.gating_token_pattern (the reference hard-codes the InternLM2 ids, moe_reward.py:45-48):
     a prompt that ends with the InternLM2 pattern raises the reference's ValueError under the Phi-3 config"""
