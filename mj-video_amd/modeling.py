@@ -590,8 +590,11 @@ class InternVLChatRewardModeling(nn.Module):
         # k | v rows of the LAST decoder layer's wqkv (trim_last_layer): rows are (kv head, [q_0 .. q_{G-1}, k, v], 128)
         lc0 = self.config.llm_config
         KV0, G0 = lc0.num_key_value_heads, lc0.num_attention_heads // lc0.num_key_value_heads
-        if not self._phi3:
-            wl = self.model.language_model.model.layers[-1].attention.wqkv.weight
+        wl = self.model.language_model.model.layers[-1].attention.wqkv.weight
+        if self._phi3:   # qkv_proj rows are [q heads | k heads | v heads]: the two projections of the trimmed last layer are row slices
+            hd0 = lc0.hidden_size // lc0.num_attention_heads
+            d["wq_last"], d["wkv_last"] = wl[:lc0.num_attention_heads * hd0], wl[lc0.num_attention_heads * hd0:]
+        else:
             d["wkv_last"] = wl.view(KV0, G0 + 2, 128, wl.shape[1])[:, G0:].reshape(KV0 * 2 * 128, wl.shape[1]).contiguous()
         if self.norm_fusion and self._phi3:
             raise NotImplementedError("norm_fusion is built for the InternLM2 tower's GEMM epilogues only")
@@ -1130,6 +1133,29 @@ class InternVLChatRewardModeling(nn.Module):
                 nt, ns = tail_rows.numel(), sel_rows.numel()
                 kv = self._buf("llm_kv_last", n, 2 * KV * hd, dev)
                 ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
+                if phi3:
+                    # [k heads | v heads] of every row (the k heads rotated in place), q heads of the tail rows only
+                    ops.gemm(hn, d["wkv_last"], kv, EPI_BIAS)
+                    ops.rope_heads(kv, KV, hd, cos, sin, positions)
+                    hn_t = self._buf("llm_hn_tail", nt, hdim, dev)
+                    q_t = self._buf("llm_q_tail", nt, H * hd, dev)
+                    att_t = self._buf("llm_att_tail", nt, H * hd, dev)
+                    ops.embed_gather(tail_rows, hn, hn_t, -1)
+                    ops.gemm(hn_t, d["wq_last"], q_t, EPI_BIAS)
+                    ops.rope_heads(q_t, H, hd, cos, sin, tail_pos)
+                    pl = prefix["kv_last"] if prefix is not None else None
+                    ops.attention(q_t, kv[:, :KV * hd], kv[:, KV * hd:], att_t, cu, max_len, H, G, hd, True, scale, mode,
+                                  cu_seqlens_q=cu_tail, max_seqlen_q=max_tail,
+                                  prefix_k=(pl[:, :KV * hd] if pl is not None else None), prefix_v=(pl[:, KV * hd:] if pl is not None else None))
+                    att_s = self._buf("llm_att_sel", ns, hdim, dev)
+                    x_s = self._buf("llm_x_sel", ns, hdim, dev)
+                    hn_s = self._buf("llm_hn_sel", ns, hdim, dev)
+                    act_s = self._buf("llm_act_sel", ns, ff, dev)
+                    ops.embed_gather(sel_in_tail, att_t, att_s, -1)
+                    ops.embed_gather(sel_rows, x, x_s, -1)
+                    ops.gemm(att_s, layer.attention.wo.weight, x_s, EPI_SCALE_RES, res=x_s)
+                    self._llm_ffn(d, li, layer, x_s, hn_s, act_s, "sel")
+                    return x_s
                 ops.gemm(hn, d["wkv_last"], kv, EPI_ROPE_QKV, rope=(cos, sin, positions, None, k, 0))
                 hn_t = self._buf("llm_hn_tail", nt, hdim, dev)
                 qkv_t = self._buf("llm_qkv_tail", nt, (H + 2 * KV) * hd, dev)
@@ -1156,7 +1182,11 @@ class InternVLChatRewardModeling(nn.Module):
                 ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
                 ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_BIAS)
                 ops.rope_heads(qkv, H + KV, hd, cos, sin, positions)
-                ops.attention(qkv[:, :H * hd], qkv[:, H * hd:(H + KV) * hd], v_view, hn, cu, max_len, H, G, hd, True, scale, mode)
+                if snapshot is not None:   # the prompt prefix's projection rows of this layer (rotated k and v in their columns)
+                    snapshot[1]["k"].append(qkv[:snapshot[0]].clone())
+                ops.attention(qkv[:, :H * hd], qkv[:, H * hd:(H + KV) * hd], v_view, hn, cu, max_len, H, G, hd, True, scale, mode,
+                              prefix_k=(pk[:, H * hd:(H + KV) * hd] if pk is not None else None),
+                              prefix_v=(pk[:, (H + KV) * hd:] if pk is not None else None))
                 if self.debug_probes is not None and li == 0:
                     self.debug_probes["llm_attn0"] = dict(q=qkv[:, :H * hd].clone(), k=qkv[:, H * hd:(H + KV) * hd].clone(),
                                                           v=v_view.clone(), out=hn.clone(), kv_heads=KV)
@@ -1174,7 +1204,7 @@ class InternVLChatRewardModeling(nn.Module):
             else:
                 ops.rmsnorm(x, layer.attention_norm.weight, hn, lc.rms_norm_eps)
                 ops.gemm(hn, layer.attention.wqkv.weight, qkv, EPI_ROPE_QKV, rope=(cos, sin, positions, q, k, G))
-            if snapshot is not None:   # the prompt prefix's keys (rotated) and values of this layer
+            if snapshot is not None and not phi3:   # the prompt prefix's keys (rotated) and values of this layer
                 snapshot[1]["k"].append(k[:snapshot[0]].clone())
                 snapshot[1]["v"].append(qkv[:snapshot[0]].clone())
             if not phi3:
@@ -1243,7 +1273,7 @@ class InternVLChatRewardModeling(nn.Module):
         not depend on the rows around it), up to fp32 re-association otherwise."""
         lc = self.config.llm_config
         P = int(prefix_ids.shape[0])
-        H, KV, hd = lc.num_attention_heads, lc.num_key_value_heads, 128
+        H, KV, hd = lc.num_attention_heads, lc.num_key_value_heads, lc.hidden_size // lc.num_attention_heads
         G = H // KV
         ids = torch.from_numpy(prefix_ids.astype(np.int32)).to(dev)
         x = self._buf("llm_x", P, lc.hidden_size, dev)
@@ -1254,12 +1284,20 @@ class InternVLChatRewardModeling(nn.Module):
         self._language_tower(d, x, cu, pos, P, None, padded_len=padded_len, snapshot=(P, store))
         # the last layer's values once more in the [k | v] column layout of the trimmed last layer (wkv_last: kv head h at
         # columns 256 h + 128 ...), copied from their wqkv columns ((G + 2) 128 h + (G + 1) 128 ...): same sums, same values
-        v_last = torch.zeros(P, 2 * KV * hd, dtype=BF16, device=dev)
-        v_last.view(P, KV, 2, hd)[:, :, 1] = store["v"][-1].view(P, KV, G + 2, hd)[:, :, G + 1]
+        if self._phi3:
+            # Phi-3 layout: store["k"][li] = the prefix rows of the layer's whole [q | k | v] projection (the live views' row stride);
+            # the trimmed last layer reads [k | v] rows of their own: the same values, copied out
+            kv_last = store["k"][-1][:, H * hd:].contiguous()
+            v_last = kv_last
+            extra = dict(kv_last=kv_last)
+        else:
+            v_last = torch.zeros(P, 2 * KV * hd, dtype=BF16, device=dev)
+            v_last.view(P, KV, 2, hd)[:, :, 1] = store["v"][-1].view(P, KV, G + 2, hd)[:, :, G + 1]
+            extra = {}
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))   # a later forward on ANOTHER stream waits for the rows to exist
         self._prefix = dict(settings=settings, ids=prefix_ids.copy(), P=P, k=store["k"], v=store["v"], v_last=v_last, ready=ready,
-                            stream=torch.cuda.current_stream(dev).cuda_stream)
+                            stream=torch.cuda.current_stream(dev).cuda_stream, **extra)
 
     # -- forward ---------------------------------------------------------------------------------
     def _forward_group(self, d, tag: str, pixel_values, host_ids, outs, lo: int, probes_ok: bool):
@@ -1279,16 +1317,15 @@ class InternVLChatRewardModeling(nn.Module):
         hdim = lc.hidden_size
         # what the cached prefix rows depend on besides their ids: the weights (as _prepare tracks them), the rotary base
         # (dynamic NTK may have replaced it), every numerics setting, and which buffer the last layer's values live in
-        # (the Phi-3 tower: the last layer's wo / FFN run on the selected rows only; its query trimming and the prefix cache are
-        # built on the InternLM2 projection layout and stay off)
-        tail_form = bool(trimmed and self.trim_last_layer and not self.norm_fusion and not self._exp8_set() and not self._phi3)
-        if self._phi3:
-            settings = None
+        tail_form = bool(trimmed and self.trim_last_layer and not self.norm_fusion and not self._exp8_set())
+        if self._phi3:   # (LongRoPE keeps no state: the tables depend on whether the padded width exceeds the original window)
+            settings = (self._derived_sig, int(input_ids.shape[1]) > lc.original_max_position_embeddings, self.attention_scores,
+                        self.ffn_format, bool(self.norm_fusion), self._exp8_set(), bool(self.use_gemm_workspace), tail_form, str(dev))
         else:
             # (the rotary base this forward WILL rotate with - the state itself advances in the tower, after the batch is validated)
             settings = (self._derived_sig, self._rope_next_state(int(input_ids.shape[1]))["base"], self.attention_scores, self.ffn_format, bool(self.norm_fusion),
                         self._exp8_set(), bool(self.use_gemm_workspace), tail_form, str(dev))
-        use_prefix = bool(self.prefix_cache and trimmed and not self._phi3)
+        use_prefix = bool(self.prefix_cache and trimmed)
         hit = []
 
         def lookup(prefix_ids: np.ndarray) -> bool:

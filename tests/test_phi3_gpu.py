@@ -234,6 +234,45 @@ def test_phi3_gqa_and_masks_against_the_oracle(cuda, kv_heads, mask_mode):
         assert float(np.abs(got - want).max()) <= tol, (f, float(np.abs(got - want).max()), tol)
 
 
+def test_phi3_trimming_and_prefix_cache_are_invisible(cuda):
+    """model.trim_last_layer / model.prefix_cache on the Phi-3 tower (its own projection layout: row slices of qkv_proj for the
+    trimmed last layer, whole [q | k | v] prefix rows per layer): with no GEMM slicing K, every CustomOutput field is BIT-IDENTICAL
+    with the two switches on (cold and warm cache) and off; the cache serves the second forward; another padded width that crosses
+    the LongRoPE window rebuilds it."""
+    from mj_video_amd import synth
+    cfg = phi3_cfg("tiny", 56, hidden_size=384, num_attention_heads=4, num_key_value_heads=4, original_max_position_embeddings=160)
+    model = build_phi3_model(cfg, synth.synth_state_dict(cfg, seed=51), cuda)
+    model.use_gemm_workspace = False
+    vids = [dict(video_idx=i, n_tiles=t, caption_seed=i) for i, t in enumerate([4, 2, 3])]
+    px, ids, mask = (t.to(cuda) for t in phi3_inputs(cfg, vids, 300, 56))
+
+    def run(cache, trim):
+        model.prefix_cache, model.trim_last_layer = cache, trim
+        return model.forward(px, ids, mask)
+
+    def same(a, b):
+        return [f for f in FIELDS if not torch.equal(getattr(a, f), getattr(b, f))]
+
+    plain = run(False, False)
+    assert same(plain, run(False, True)) == []                       # queries only where the heads read
+    model._prefix = None
+    hits = model.prefix_cache_hits
+    cold = run(True, True)
+    assert model._prefix is not None and model._prefix["P"] == 64 and model.prefix_cache_hits == hits
+    warm = run(True, True)
+    assert model.prefix_cache_hits == hits + 1
+    assert same(plain, cold) == [] and same(plain, warm) == [] and same(plain, run(True, False)) == []
+    # a batch whose padded width crosses the original window (160) rotates with the LONG factors: another cache entry
+    vids2 = [dict(video_idx=7, n_tiles=8, caption_seed=9)]
+    px2, ids2, mask2 = (t.to(cuda) for t in phi3_inputs(cfg, vids2, 300, 56))
+    assert ids.shape[1] <= 160 < ids2.shape[1]
+    before = model._prefix
+    long_on = model.forward(px2, ids2, mask2)
+    assert model._prefix is not before
+    model.prefix_cache = model.trim_last_layer = False
+    assert same(long_on, model.forward(px2, ids2, mask2)) == []
+
+
 def test_phi3_errors_and_pattern(cuda):
     """the gating rows are found by config.gating_token_pattern (the reference hard-codes the InternLM2 ids, moe_reward.py:45-48):
     a prompt that ends with the InternLM2 pattern raises the reference's ValueError under the Phi-3 config"""
