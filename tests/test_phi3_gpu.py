@@ -321,7 +321,7 @@ def test_phi3_single_layer_at_4b_dims(cuda, name, scores):
     assert d_ref <= 2.0 * noise and d_f32 <= 2.0 * noise, (name, d_ref, d_f32, noise)
 
 
-@pytest.mark.parametrize("size", [224])
+@pytest.mark.parametrize("size", [224, 448])
 def test_phi3_full_4b_dims_against_golden(cuda, size):
     """tests/golden/phi3_full_<size>.npz: InternVL2-4B dims end to end (4.1 G parameters), 8 frames per video, all videos of the
     fixture in one forward: layer probes within 2 x the reference's own bf16-vs-fp32 distance at that layer, hidden rows within 1.5 x the
