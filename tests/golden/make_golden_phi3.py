@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import mj_video_amd  # noqa: E402,F401
 from mj_video_amd import configuration as C, synth  # noqa: E402
-from oracle import ref_cpu, ref_phi3, reference_shim as RS  # noqa: E402
+from oracle import ref_phi3, reference_shim as RS  # noqa: E402
 from make_golden import FIELDS, _bits, check_equal, n_img_tokens, run_reference, to_np  # noqa: E402
 
 TK = synth.PHI3_TOKENS

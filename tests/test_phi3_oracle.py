@@ -10,7 +10,7 @@ import torch
 
 from util import FIELDS, load_golden
 from mj_video_amd import configuration as C, synth
-from oracle import ref_cpu, ref_phi3
+from oracle import ref_phi3
 
 TK = synth.PHI3_TOKENS
 

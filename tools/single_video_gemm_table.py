@@ -8,7 +8,7 @@ os.environ.setdefault("MJV_LIBRARY", os.path.join(ROOT, "mj-video_amd", "libmjv_
 sys.path.insert(0, ROOT)
 import torch
 from mj_video_amd import ops
-from mj_video_amd._lib import EPI_SCALE_RES, EPI_BIAS, load_library, check
+from mj_video_amd._lib import EPI_SCALE_RES, load_library, check
 dev, BF = "cuda", torch.bfloat16
 lib = load_library()
 ws = torch.empty(ops.gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
