@@ -156,6 +156,31 @@ def test_attention_head_dim_96_race_screen(cuda):
         assert torch.equal(first, again)
 
 
+def test_attention_head_dim_96_long_context(cuda):
+    """BASELINE configs[3]'s sequence length on the Phi-3 heads: one causal sequence of 28 810 tokens (16 frames x 7 tiles x 256 +
+    text), head_dim 96, both numerics; the fp32 reference is evaluated in query chunks for the first / middle / last rows."""
+    from mj_video_amd import ops
+    D, H, L = 96, 2, 28810
+    q, k, v = rnd(L, H * D, seed=1), rnd(L, H * D, seed=2), rnd(L, H * D, seed=3)
+    cu = torch.tensor([0, L], dtype=torch.int32, device=cuda)
+    scale = float(np.float32(D ** -0.5))
+    rows = torch.cat([torch.arange(0, 70), torch.arange(14000, 14130), torch.arange(L - 200, L)])
+    for mode in (1, 2):
+        out = torch.empty(L, H * D, dtype=BF, device=cuda)
+        ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), out, cu, L, H, 1, D, True, scale, mode)
+        o = out.float().cpu()
+        assert torch.isfinite(o).all()
+        for h in range(H):
+            sc = q[rows, h * D:(h + 1) * D].float() @ k[:, h * D:(h + 1) * D].float().t()
+            sc = (sc.to(BF).float() * scale).to(BF).float() if mode == 1 else sc * scale
+            sc = sc.masked_fill(torch.arange(L)[None, :] > rows[:, None], float("-inf"))
+            ref = (torch.softmax(sc, -1).to(BF).float() @ v[:, h * D:(h + 1) * D].float()).to(BF).float()
+            got = o[rows, h * D:(h + 1) * D]
+            rel = (got - ref).norm() / ref.norm()
+            assert rel.item() < 6e-3, (mode, h, rel.item())
+            assert (got - ref).abs().max().item() < 0.03
+
+
 # ------------------------------------------------------------------------------------------------ model
 @pytest.mark.parametrize("scores", ["flash", "eager"])
 def test_phi3_tiny_cases_against_golden(cuda, scores):
