@@ -382,6 +382,11 @@ def main():
                          "switches in `config` and carries this setting as `secondary.prefix_cache_off`")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` legs (fp8 FFN path, the 8-pair shard, the 112-tile config) of the default N = 1 run")
+    ap.add_argument("--backbone", choices=["2b", "4b"], default="2b",
+                    help="4b: BASELINE configs[4]'s backbone (InternVL2-4B = InternViT + Phi-3-mini) with the 28-criteria MoE heads instead of "
+                         "MJ-VIDEO-2B - its own line (metric, config.baseline_config, its own algorithmic flops), never the headline; with "
+                         "--gpus 8 it is configs[4]'s 8-GPU form (8 pairs per GPU, one RCCL all-gather); combine with --fp8 / --fp8-preset")
+    ap.add_argument("--fp8-preset", default="mxfp8", help="with --fp8: 'mxfp8' (all four FFN Linears), 'mxfp8-rank999', 'mxfp8-vit' or 'mxfp8:<a>+<b>'")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4]'s weight path on the 2B stand-in: the five FFN Linears of both towers on MXFP8 (e4m3, "
                          "block-32 e8m0 scales) operands, fp32 accumulate (model.set_ffn_format('mxfp8')).  Its own line, its own "
@@ -421,14 +426,16 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     S, F = args.image_size, args.frames
-    cfg = C.InternVLChatRewardModelingConfig(**C.mjvideo_2b_config_dict(S), **C.mjvideo_head_kwargs())
+    four_b = args.backbone == "4b"
+    tk = synth.PHI3_TOKENS if four_b else synth.INTERNLM2_TOKENS
+    cfg = C.InternVLChatRewardModelingConfig(**(C.internvl2_4b_config_dict(S) if four_b else C.mjvideo_2b_config_dict(S)), **C.mjvideo_head_kwargs())
     model = InternVLChatRewardModeling.from_config(cfg, dtype=torch.bfloat16, device=dev)
     random_init_on_device(model, cfg, dev, seed=1234)
-    model.config.pad_token_id = synth.PAD_ID
-    model.model.img_context_token_id = synth.IMG_CONTEXT_ID
+    model.config.pad_token_id = tk.pad
+    model.model.img_context_token_id = tk.img_context
     model.eval()
     if args.fp8:
-        model.set_ffn_format("mxfp8")
+        model.set_ffn_format(args.fp8_preset)
     if args.no_prefix_cache:
         model.prefix_cache = model.trim_last_layer = False
     if os.environ.get("MJV_BENCH_VIT_CHUNK"):     # A/B (round 6): the vision tower over this many tiles at a time
@@ -444,9 +451,9 @@ def main():
     px = torch.randn(n_videos * F, 3, S, S, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
     ids_list = []
     for p in range(args.pairs):
-        row = synth.synth_input_ids(per_tile * F, caption_seed=rank * 1000 + p)
+        row = synth.synth_input_ids(per_tile * F, caption_seed=rank * 1000 + p, tokens=tk)
         ids_list += [row, row]  # both videos of a pair share the caption
-    ids, mask = synth.pad_batch(ids_list)
+    ids, mask = synth.pad_batch(ids_list, pad_id=tk.pad)
     ids, mask = ids.to(dev), mask.to(dev)
     seq_len = int(ids.shape[1])
     global_pairs = list(range(world * args.pairs))   # pair ids of the whole batch; rank r owns a contiguous block of them
@@ -515,12 +522,14 @@ def main():
     if rank == 0:
         total_pairs = args.pairs * world * args.steps
         value = total_pairs / elapsed
+        algo_pair = 2 * algorithmic_tflop_per_video(cfg, F, seq_len, S) if four_b else ALGO_TFLOP_PER_PAIR
         line = {
-            "metric": METRIC,
+            "metric": (METRIC if not four_b else "video-pairs scored/sec, InternVL2-4B backbone + 28-criteria MoE heads "
+                                                 "(BASELINE configs[4]; NOT the headline metric), 8-frame, 1/2/4/8 MI355X"),
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("fp8-e4m3 (MXFP8, block-32 e8m0 scales) operands + fp32 accumulate in the FFN GEMMs, bf16 elsewhere"
+            "dtype": (f"fp8-e4m3 (MXFP8, block-32 e8m0 scales) operands + fp32 accumulate in the FFN GEMMs (preset {args.fp8_preset}), bf16 elsewhere"
                       if args.fp8 else "bf16"),
             "data": "synthetic", "ranks_seen": ranks_seen,
             "ms_per_step_by_rank": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
@@ -528,12 +537,15 @@ def main():
             "norm_fusion": bool(model.norm_fusion), "vit_chunk_tiles": getattr(model, "vit_chunk_tiles", None),
             "attention_scores": model.attention_scores,
             "process_group": ("nccl" if use_dist else None),
-            "config": {"workload": (f"MJ-VIDEO-2B, batch={args.pairs * world} pairs"
+            "config": {"workload": (("InternVL2-4B backbone (InternViT + Phi-3-mini) + 28-criteria MoE heads" if four_b else "MJ-VIDEO-2B")
+                                    + f", batch={args.pairs * world} pairs"
                                     + (f" sharded DP over {world} MI355X ({args.pairs} pairs per GPU), RCCL all-gather rewards"
                                        if world > 1 else " on 1 MI355X")
                                     + f", {F} frames @{S}^2 max_num=1, N={seq_len} tokens/video, random-init weights, inputs "
                                       "resident in HBM"),
-                       "baseline_config": ("configs[4] weight path on the 2B stand-in (no 4B reference exists): FFN GEMMs only; NOT the headline"
+                       "baseline_config": (("configs[4]: InternVL2-4B backbone" + (", fp8 MFMA weight path" if args.fp8 else ", bf16")
+                                            + (", 8 MI355X" if world == 8 else f", {world} MI355X") + "; NOT the headline") if four_b else
+                                           "configs[4] weight path on the 2B model: FFN GEMMs only; NOT the headline"
                                            if args.fp8 else "configs[1]" if (world, args.pairs, S, F) == (1, 4, 448, 8) else
                                            "configs[2] shard size (8 pairs per GPU; 64 pairs at 8 GPUs)"
                                            if (args.pairs, S, F) == (8, 448, 8) and world > 1 else "other"),
@@ -560,14 +572,14 @@ def main():
             # pair minus what this run's switches leave out of the language tower
             left_out = 2 * executed_tflop_per_video(cfg, seq_len, (model._prefix or {}).get("P", 0) if model.prefix_cache else 0,
                                                     bool(model.trim_last_layer))
-            line["executed_tflop_per_pair"] = round(ALGO_TFLOP_PER_PAIR - left_out, 3)
-            line["frac_of_mfma_roofline"] = round(value * (ALGO_TFLOP_PER_PAIR - left_out) / (MFMA_BF16_PEAK_TFLOPS * world), 4)
+            line["executed_tflop_per_pair"] = round(algo_pair - left_out, 3)
+            line["frac_of_mfma_roofline"] = round(value * (algo_pair - left_out) / (MFMA_BF16_PEAK_TFLOPS * world), 4)
             line["frac_of_mfma_roofline_note"] = (
-                f"value x executed TFLOP per pair / 2.5 PFLOP/s: {ALGO_TFLOP_PER_PAIR} algorithmic (SURVEY.md §8(d)) minus {left_out:.3f} "
+                f"value x executed TFLOP per pair / 2.5 PFLOP/s: {algo_pair:.2f} algorithmic (SURVEY.md §8(d)) minus {left_out:.3f} "
                 "this run leaves out of the language tower (cached prompt-prefix rows in every layer; last decoder layer: q projection + "
                 "attention beyond the rows the heads read, wo / FFN on every other row).  `value_all_work` = the same batch with "
                 "prefix_cache / trim_last_layer off (every row in every forward), `frac_all_work` its fraction on ITS executed flops")
-            line["pairs_per_s_roofline"] = round(MFMA_BF16_PEAK_TFLOPS * world / ALGO_TFLOP_PER_PAIR, 2)
+            line["pairs_per_s_roofline"] = round(MFMA_BF16_PEAK_TFLOPS * world / algo_pair, 2)
             line["value_all_work"] = None
         else:
             line["frac_of_mfma_roofline"] = None
@@ -612,7 +624,7 @@ def main():
             line["roofline"] = roofline(res, args.steps, share_from=res_all)
             line["roofline"]["note"] = "events around this kernel's launches on the launch stream inside the timed region"
             line["kernels"] = table(res_all, 1)
-        if world == 1 and not args.no_latency and not args.fp8:
+        if world == 1 and not args.no_latency and not args.fp8 and not four_b:
             # the reference's real call pattern: ONE video per forward (eval_genai_mjvideo.py:140-141), fresh ids each time
             px1, ids1, mask1 = px[:F].contiguous(), ids[:1].contiguous(), mask[:1].contiguous()
             for _ in range(2):
@@ -631,7 +643,7 @@ def main():
             line["latency"] = {"one_video_per_forward_ms": round(lat_ms, 3), "host_enqueue_ms": round(host_ms, 3),
                                "pairs_per_s_at_batch_1_video": round(0.5e3 / lat_ms, 3),
                                "note": "back-to-back single-video forwards, not part of `value`"}
-        if (world == 1 and not use_dist and not args.no_secondary and not args.fp8 and (S, F, args.pairs) == (448, 8, 4)
+        if (world == 1 and not use_dist and not args.no_secondary and not args.fp8 and not four_b and (S, F, args.pairs) == (448, 8, 4)
                 and not os.environ.get("MJV_BENCH_NORM_FUSION") and not os.environ.get("MJV_BENCH_VIT_CHUNK") and not args.gemm_code):
             line["secondary"] = secondary_legs(model, cfg, dev, px, ids, mask)
             off = line["secondary"].get("prefix_cache_off")
@@ -640,7 +652,7 @@ def main():
                 line["value_all_work"] = off["value"]
                 line["frac_all_work"] = round(off["value"] * (ALGO_TFLOP_PER_PAIR - lo) / MFMA_BF16_PEAK_TFLOPS, 4)
                 off["frac_of_mfma_roofline"] = line["frac_all_work"]
-        if world == 1 and not args.no_cpu_baseline and not args.fp8:
+        if world == 1 and not args.no_cpu_baseline and not args.fp8 and not four_b:
             # oneDNN bf16 GEMMs stop scaling (and oversubscribe NUMA domains) far below a 256-thread host: cap at 32
             cpu_model, phys, logical = host_cpu_info()
             threads = min(phys, 32)
