@@ -1,6 +1,6 @@
 """How exact is the accumulation inside v_mfma_scale_f32_16x16x128_f8f6f4?  Random MXFP8 operands through mjv_gemm_bf16 (MXFP8
 operands, bf16 output), the exact sum of the dequantised operands in fp64, and the part of the error that one bf16 ulp of the
-output does not explain, relative to sum|a||w| (profiles/r04_c_mfma_fp8_accumulation.txt; tools only)."""
+output does not explain, relative to sum|a||w| (profiles/r04_c_mfma_fp8_accumulation.txt; a calibration script of the fp8 tests: it lives under tests/ because it calls the oracle)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The TAIL of the accumulation error of v_mfma_scale_f32_16x16x128_f8f6f4 (tools/mfma_fp8_accumulation.py looked at 65 k outputs
+"""The TAIL of the accumulation error of v_mfma_scale_f32_16x16x128_f8f6f4 (tests/diag_mfma_fp8_accumulation.py looked at 65 k outputs
 per setting; tools/fuzz_kernels.py found one output in 3.7e11 a little beyond the bound that sample suggested).  Here: ~1e9 outputs
 per setting, exact reference in fp64 on the GPU, the part of the error one bf16 ulp does not explain relative to (a) sum|a||w| and
 (b) 128 x the largest |a w| product of the row - the quantity a fixed-point adder aligned to the largest term would be bounded by."""

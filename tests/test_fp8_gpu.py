@@ -92,13 +92,13 @@ def test_norms_mxfp8_equal_bf16_norm_then_quantise(cuda, rows, dim):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
-# Measured (tools/mfma_fp8_accumulation.py, profiles/r04_c_mfma_fp8_accumulation.txt): the sum of the 128 products INSIDE one
+# Measured (tests/diag_mfma_fp8_accumulation.py, profiles/r04_c_mfma_fp8_accumulation.txt): the sum of the 128 products INSIDE one
 # v_mfma_scale_f32_16x16x128_f8f6f4 is not a sequential fp32 sum - on random operands it is off by up to 2^-17 of sum|a||w|
 # (K = 128; 2^-19 at K = 1024), against 2^-24.7 for torch's fp32 matmul.  An output with heavy cancellation (|sum| << sum|a||w|)
 # is therefore several bf16 ulps of ITSELF away from the exact sum although every product is exact.  The tolerance of the
 # random-operand tests is stated accordingly: one bf16 ulp of the exact result + 2^-14 * sum|a||w|.  (The 2^-17 is the maximum over
 # 65 k outputs; the distribution has a tail: over 5e8 outputs at K = 128 the maximum is 2^-14.9, 83 beyond 2^-16, ONE beyond 2^-15 -
-# tools/mfma_fp8_accumulation_tail.py, profiles/r04_u_mfma_fp8_accumulation_tail.txt, found after a 1.6-million-case fuzz run reported
+# tests/diag_mfma_fp8_accumulation_tail.py, profiles/r04_u_mfma_fp8_accumulation_tail.txt, found after a 1.6-million-case fuzz run reported
 # one output of 3.7e11 beyond the old 2^-15; per output the excess is 2^-18.6 x 128 x its largest |a w| product, what an adder
 # aligned to the largest term would do.)
 ACC_TOL = 2.0 ** -14

@@ -99,11 +99,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 def test_product_never_imports_the_oracle():
-    pkg = os.path.join(ROOT, "mj-video_amd")
-    for f in os.listdir(pkg):
-        if f.endswith(".py"):
-            src = open(os.path.join(pkg, f)).read()
-            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import anything under oracle/: every other
+    Python file of the tree (the package, tools/, scripts/) is scanned"""
+    allowed_files = {os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    allowed_dirs = tuple(os.path.join(ROOT, d) + os.sep for d in ("tests", "oracle", "gpurun_out", ".git"))
+    seen = 0
+    for dirpath, _, files in os.walk(ROOT):
+        if (dirpath + os.sep).startswith(allowed_dirs):
+            continue
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py") and path not in allowed_files:
+                seen += 1
+                src = open(path).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), path
+    assert seen > 20
+    # ... and in the two allowed files the import sits inside the function that is allowed to check with it
+    for path, fn in ((os.path.join(ROOT, "bench.py"), "cpu_baseline"), (os.path.join(ROOT, "__graft_entry__.py"), "smoke")):
+        src = open(path).read()
+        for m in re.finditer(r"^(\s*)(from|import)\s+oracle", src, re.M):
+            assert m.group(1), (path, "module-level oracle import")
+            head = src[:m.start()]
+            last_def = re.findall(r"^def (\w+)", head, re.M)[-1]
+            assert last_def == fn or fn == "smoke" and last_def.startswith(("smoke", "_smoke")), (path, last_def)
 
 
 # ------------------------------------------------------------------------------------- prompt logic
