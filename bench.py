@@ -555,11 +555,11 @@ def main():
                                         "`--gpus 1 --pairs 8` as its baseline"),
                        "ids": "fresh id / mask tensors every step (one device->host copy of the ids per forward)",
                        # steady-state work removal a scorer is entitled to, STATED: the keys / values of the
-                       # constant prompt prefix (first 64 k tokens: system prompt + "Frame1: <img>") come from a cache filled by
+                       # constant prompt prefix (a multiple of 64 tokens: system prompt + "Frame1: <img>") come from a cache filled by
                        # the first forward, and the last decoder layer computes queries only from the first selected row on.
                        # secondary.prefix_cache_off is the same workload with both off (every row, every forward)
-                       "prefix_cache_note": ("steady-state work removal, stated: the keys / values of the prompt's constant first 64 k tokens "
-                                             "(system turn + 'Frame1: <img>') come from a per-model cache filled once by a pass over those "
+                       "prefix_cache_note": ("steady-state work removal, stated: the keys / values of the prompt's constant first tokens "
+                                             "(system turn + 'Frame1: <img>', cut to a multiple of 64: prefix_cache_tokens) come from a per-model cache filled once by a pass over those "
                                              "tokens alone, and the last decoder layer computes queries only from the first row the heads "
                                              "read; outputs equal the full computation up to fp32 re-association (bit for bit when no GEMM "
                                              "slices K); secondary.prefix_cache_off = both switches off, every row in every forward"),
@@ -592,7 +592,9 @@ def main():
 
             traffic, traffic_note = {}, None
             tpaths = sorted(p_ for p_ in os.listdir(os.path.join(ROOT, "profiles")) if p_.endswith("_pmc_traffic.json"))
-            if (S, F, args.pairs) == (448, 8, 4) and tpaths:   # the latest round's committed PMC passes of this workload
+            if four_b:   # the PMC passes were collected on the 2B workload: other launch shapes under the same kernel names
+                traffic_note = "not collected for the InternVL2-4B backbone's launch shapes (profiles/*_pmc_traffic.json is the 2B workload)"
+            elif (S, F, args.pairs) == (448, 8, 4) and tpaths:   # the latest round's committed PMC passes of this workload
                 tj = json.load(open(os.path.join(ROOT, "profiles", tpaths[-1])))
                 if tj.get("source_sha1") == kernel_sources_sha1():
                     traffic = tj.get("per_launch_bytes", {})
@@ -652,6 +654,9 @@ def main():
                 line["value_all_work"] = off["value"]
                 line["frac_all_work"] = round(off["value"] * (ALGO_TFLOP_PER_PAIR - lo) / MFMA_BF16_PEAK_TFLOPS, 4)
                 off["frac_of_mfma_roofline"] = line["frac_all_work"]
+        if world == 1 and (args.fp8 or four_b):
+            line["cpu_baseline"] = {"value": None, "note": "timed on the headline line only (default `python bench.py`: the oracle's bf16 forward of "
+                                                            "MJ-VIDEO-2B on the host cores); this line is a secondary configuration"}
         if world == 1 and not args.no_cpu_baseline and not args.fp8 and not four_b:
             # oneDNN bf16 GEMMs stop scaling (and oversubscribe NUMA domains) far below a 256-thread host: cap at 32
             cpu_model, phys, logical = host_cpu_info()
