@@ -591,9 +591,12 @@ def main():
             res = ops.prof_results()
 
             traffic, traffic_note = {}, None
-            tpaths = sorted(p_ for p_ in os.listdir(os.path.join(ROOT, "profiles")) if p_.endswith("_pmc_traffic.json"))
-            if four_b:   # the PMC passes were collected on the 2B workload: other launch shapes under the same kernel names
-                traffic_note = "not collected for the InternVL2-4B backbone's launch shapes (profiles/*_pmc_traffic.json is the 2B workload)"
+            # (the 2B workload's passes are profiles/rNN_pmc_traffic.json; the 4B backbone's launch shapes have their own file,
+            # profiles/rNN_4b_pmc_traffic.json - same kernel names, other shapes)
+            tpaths = sorted(p_ for p_ in os.listdir(os.path.join(ROOT, "profiles"))
+                            if p_.endswith("_pmc_traffic.json") and p_.endswith("_4b_pmc_traffic.json") == four_b)
+            if four_b and (args.fp8 or not tpaths):   # (the 4B passes ran the bf16 line: the fp8 line's bf16 GEMMs take other inputs)
+                traffic_note = "not collected for this line's launch shapes (profiles/*_pmc_traffic.json: the 2B workload; *_4b_*: the 4B backbone in bf16)"
             elif (S, F, args.pairs) == (448, 8, 4) and tpaths:   # the latest round's committed PMC passes of this workload
                 tj = json.load(open(os.path.join(ROOT, "profiles", tpaths[-1])))
                 if tj.get("source_sha1") == kernel_sources_sha1():

@@ -10,9 +10,12 @@ from collections import defaultdict
 
 import json
 json_out = None
+workload = "C2 workload"
 args = sys.argv[1:]
 if args and args[0] == "--json":
     json_out, args = args[1], args[2:]
+if args and args[0] == "--workload":     # what the passes ran (goes into the json's "source" text)
+    workload, args = args[1], args[2:]
 EPI = ["bias", "bias_gelu", "bias_relu", "scale_res", "silu_mul", "rope_qkv"]
 
 
@@ -44,7 +47,7 @@ def tag_of(k):
     m = re.match(r"(?:v2::attn2_kernel|attn_kernel)<(\d+), (true|false)", k)
     if m:
         return f"attn_d{m.group(1)}" + ("_causal" if m.group(2) == "true" else "")
-    for name in ("layernorm", "rmsnorm", "row_stats", "quantize_mxfp8", "rope_split", "patchify", "embed_gather", "reward_heads", "cls_rows"):
+    for name in ("layernorm", "rmsnorm", "row_stats", "quantize_mxfp8", "rope_split", "rope_heads", "patchify", "embed_gather", "reward_heads", "cls_rows"):
         if k.startswith(name):
             return name
     return None
@@ -88,7 +91,7 @@ if json_out:
             h.update(fn.encode())
             h.update(open(os.path.join(csrc, fn), "rb").read())
     json.dump({"source_sha1": h.hexdigest(),   # kernel sources these counters were collected on (bench.py checks it)
-               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh), C2 workload; "
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh), " + workload + "; "
                          "traffic per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes): the factor 2 is the gfx950 FETCH_SIZE "
                          "correction of MI355X_MICROARCH.md; counted at the L2<->fabric boundary, Infinity-Cache hits included",
                "per_launch_bytes": per}, open(json_out, "w"), indent=1)
