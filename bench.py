@@ -359,6 +359,9 @@ def kernel_sources_sha1():
 
 
 def main():
+    # dmabuf IPC is the only kind this pool's host driver supports (RCCL init across processes fails without it); exported on the
+    # GPU boxes already - set here too, before the first HIP call, for a launcher that starts the ranks with a scrubbed environment
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
