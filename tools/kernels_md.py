@@ -60,14 +60,16 @@ F8 = [
 ]
 
 
-def mfma_busy():
-    """tag -> MFMA-pipe busy share from the committed PMC summary (tools/mfma_busy_summary.py), if there is one"""
+def mfma_busy(suffix=""):
+    """tag -> MFMA-pipe busy share from the committed PMC summary (tools/mfma_busy_summary.py), if there is one
+    (suffix "_4b": the passes over bench.py --backbone 4b)"""
     import glob
     import re
     out = {}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_pipe_busy.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_mfma_pipe_busy{suffix}.txt")))
     if not files:
         return out
+    out["_file"] = os.path.relpath(files[-1], ROOT)
     epi = ["bias", "bias_gelu", "bias_relu", "scale_res", "silu_mul", "rope_qkv"]
     for ln in open(files[-1]):
         m = re.match(r"t256::gemm256p?_kernel<(\d), 0.*\s(\d\.\d+)\s*$", ln)
@@ -157,6 +159,11 @@ def main():
             if r.get("value"):
                 top = "; ".join(f"`{t}` {v['ms_per_step']:.1f}" + (f" @ {v['tflops']:.0f}" if v.get('tflops') else "") for t, v in list(r["kernels"].items())[:6])
                 w(f"| {label} | {r['value']:.2f} | {r['ms_per_step']:.1f} | {r['frac_of_bf16_mfma_roofline']} | {top} |")
+        b4 = mfma_busy("_4b")
+        if b4:
+            f4 = b4.pop("_file")
+            w(f"\nMFMA pipe busy share by the PMC counters on this configuration's bf16 line (`{f4}`): "
+              + ", ".join(f"`{k}` {v:.2f}" for k, v in b4.items()) + ".")
         w("\n`attn_d96_causal` = the head_dim 96 instantiation of the attention kernel (ABI 7); `rope_heads` = the rotary embedding in place on "
           "`qkv_proj`'s [q ∣ k ∣ v] columns (HBM-bound, not fused: DESIGN §5, docs/rounds/r06.md §2).")
     w("\nNot on this page because they are not on the scoring path's clock: `preprocess.hip` (device-side `load_video` resize: 0.44 ms per "
